@@ -1,0 +1,200 @@
+/*
+ * rt_api.h -- C ABI of the MI355X (gfx950) renderer for raytracer_cpp's per-pixel trace loop.
+ *
+ * The reference has no FFI seam: the path is entered by the direct call
+ *     DrawScene(Bitmap*, int partitions, bool antialias)        raytracer_cpp/main.cpp:190 (called :248)
+ * which reads the globals sceneObjects / pCamera (main.cpp:18-19) and fills the caller's Bitmap
+ * through PutPixel (writebitmap.h:55-71).  This header is the seam a maintainer would bind to
+ * replace that one call: upload the scene + camera once, render, download the framebuffer into
+ * Bitmap::pData.  Everything is plain C: PODs, pointers and sizes; no C++/torch types.
+ *
+ * Conventions
+ *   - every call returns RT_OK (0) or a negative rt_status; nothing throws or aborts.
+ *   - the library copies what it is handed; the caller keeps ownership of its arrays.
+ *   - a context is bound to ONE device (one process per GPU; multi-GPU = one context per rank,
+ *     each rendering a row band, see rt_render_params.row_begin/row_end and INTEGRATION.md).
+ *   - a context is not re-entrant; distinct contexts may be used from distinct threads.
+ *   - there is NO CPU fallback: without a usable HIP device rt_create fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_NO_DEVICE = -2,     /* no HIP device / runtime unusable: the product has no CPU path  */
+    RT_ERR_HIP = -3,           /* a HIP call failed; text in rt_last_error                       */
+    RT_ERR_BUFFER_TOO_SMALL = -4,
+    RT_ERR_NO_SCENE = -5,      /* rt_render before rt_upload_scene                               */
+    RT_ERR_NO_FRAME = -6,      /* rt_download_framebuffer before rt_render                       */
+    RT_ERR_LIMIT = -7          /* scene exceeds a documented limit (objects, emitters, depth)    */
+} rt_status;
+
+/* Mirrors struct Material, raytracer_cpp/sceneobjects.h:3-9 (40 bytes, same field order). */
+typedef struct rt_material {
+    float albedo[3];
+    float specular[3];
+    float reflectance;
+    float emissive[3];
+} rt_material;
+
+/* Mirrors enum class SceneObjectType, sceneobjects.h:11-15. */
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_TILED_PLANE = 1 };
+
+/*
+ * POD flattening of one SceneObject (sceneobjects.h:17-131), in LIST ORDER: the order of the
+ * array is semantic (nearest-hit ties go to the lower index, main.cpp:71-79; lights are summed in
+ * list order, main.cpp:112-184).
+ *   sphere      (Sphere,     sceneobjects.h:36-74):   a = center, radius, mat = material
+ *   tiled plane (TiledPlane, sceneobjects.h:88-131):  a = origin, b = normal,
+ *                                                     mat = whiteMat (even tiles), mat2 = blackMat
+ * Fields the reference leaves uninitialised (Material::emissive before main.cpp:45, both
+ * TiledPlane materials) must be passed as 0.
+ */
+typedef struct rt_object {
+    int32_t type;
+    float a[3];
+    float b[3];
+    float radius;
+    rt_material mat;
+    rt_material mat2;
+} rt_object;
+
+/* The eight fields of struct Camera, raytracer_cpp/camera.h:6-16, as its constructor
+ * (camera.h:18-45) leaves them.  rt_camera_init below is that constructor. */
+typedef struct rt_camera {
+    float position[3];
+    float view_direction[3];
+    float right[3];
+    float up[3];
+    float aspect_ratio;
+    float half_angle;
+    float image_width;
+    float image_height;
+} rt_camera;
+
+/* Output planes rt_render fills (bit flags). */
+enum {
+    RT_OUT_RGBA8 = 1,   /* 4 B/px: r,g,b as PutPixel would store them (main.cpp:213-216), a = 255 */
+    RT_OUT_F32X4 = 2    /* 16 B/px: radiance after the 1/numSamples scale (main.cpp:210), w = 1   */
+};
+
+/* Download formats. */
+enum {
+    RT_FMT_RGB8 = 0,    /* exactly Bitmap::pData: W*y+x, 3 bytes r,g,b, top-down (writebitmap.h:5-17) */
+    RT_FMT_RGBA8 = 1,
+    RT_FMT_F32X4 = 2,
+    RT_FMT_BMP_BODY = 3 /* BMP pixel array as WriteBitmap emits it after the 54-byte header
+                           (writebitmap.h:161-178): bottom-up, b,g,r, rows padded to 4 bytes    */
+};
+
+/* Arithmetic contract of the trace kernel. */
+enum {
+    RT_MODE_EXACT = 0,  /* bit-identical to the reference built with -ffp-contract=off: reference
+                           operation order, IEEE div/sqrt, deepest-first shading                 */
+    RT_MODE_FAST = 1    /* FMA contraction + throughput accumulator; radiance within 1e-4 rel    */
+};
+
+typedef struct rt_render_params {
+    int32_t width;          /* pixel loop bounds (ImageWidth / ImageHeight, main.cpp:12-13)       */
+    int32_t height;
+    int32_t max_depth;      /* MAX_DEPTH, main.cpp:16: recursion while depth < max_depth          */
+    int32_t spp;            /* numSamples, main.cpp:200: 1..64                                    */
+    const float *sample_offsets; /* 2*spp floats (x,y); NULL = the reference pattern
+                                    {(.1,.2),(.6,.5),(.8,.7),(.2,.8)} (main.cpp:202), spp 1 or 4   */
+    int32_t row_begin;      /* render rows [row_begin,row_end); 0,0 = whole image                 */
+    int32_t row_end;
+    int32_t outputs;        /* RT_OUT_* flags; 0 = RT_OUT_RGBA8                                   */
+    int32_t mode;           /* RT_MODE_*                                                          */
+    int32_t collect_stats;  /* non-zero: count rays/tests in-kernel (slower; rt_get_stats)        */
+} rt_render_params;
+
+typedef struct rt_stats {
+    uint64_t primary_rays;      /* W * rows * spp                                                 */
+    uint64_t reflection_rays;   /* recursive TraceRay invocations, main.cpp:108                   */
+    uint64_t shadow_rays;       /* one per (hit, emissive object): the pruned count               */
+    uint64_t hits;              /* TraceRay calls that found an object                            */
+    uint64_t lit;               /* light contributions added, main.cpp:183                        */
+    uint64_t sphere_tests;      /* ray-sphere tests the pruned algorithm requires                 */
+    uint64_t plane_tests;
+    uint64_t n_objects;
+    uint64_t n_emitters;
+    double kernel_ms;           /* device time of the last rt_render (HIP events)                 */
+} rt_stats;
+
+typedef struct rt_context rt_context;
+
+/* Opens a context on HIP device `device_id`.  Replaces nothing in the reference (it has no
+ * device); owns the device copies of the scene, the framebuffer planes and one stream. */
+int rt_create(rt_context **out, int device_id);
+void rt_destroy(rt_context *ctx);
+
+/* Replaces the globals sceneObjects / pCamera (main.cpp:18-19) as filled by InitScene
+ * (main.cpp:21-63).  May be called again between renders (camera sweeps). */
+int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n_objs, const rt_camera *cam);
+
+/* Replaces DrawScene (main.cpp:190-228).  Returns after the frame is complete on the device, so
+ * host-side chrono timing around it compares with the reference's timing (main.cpp:246-253). */
+int rt_render(rt_context *ctx, const rt_render_params *params);
+
+/* Replaces the PutPixel side effects of DrawScene: copies rows [row_begin,row_end) of the last
+ * render into a caller-allocated buffer (dst_bytes >= rows * width * bytes-per-pixel). */
+int rt_download_framebuffer(rt_context *ctx, void *dst, size_t dst_bytes, int32_t format);
+
+/* Device pointer of an output plane of the last render (band rows only, row_begin first), for
+ * device-side assembly (RCCL gather) without a host round trip.  Valid until the next
+ * rt_render/rt_destroy on this context. */
+int rt_framebuffer_device_ptr(rt_context *ctx, int32_t plane, void **out_ptr, size_t *out_bytes);
+
+/* Lets the caller own the output planes (e.g. a slice of a gather buffer).  NULL = library-owned.
+ * `bytes` must cover the band of the next render. */
+int rt_bind_framebuffer(rt_context *ctx, int32_t plane, void *device_ptr, size_t bytes);
+
+/* Stream the caller's work should be ordered against (hipStream_t as void*). */
+int rt_get_stream(rt_context *ctx, void **out_stream);
+/* Enqueue-only render: like rt_render but returns without waiting; rt_sync waits.  The trace
+ * kernel's HIP events are still recorded and read by rt_get_stats after rt_sync. */
+int rt_render_async(rt_context *ctx, const rt_render_params *params);
+int rt_sync(rt_context *ctx);
+
+int rt_get_stats(rt_context *ctx, rt_stats *out);
+const char *rt_last_error(rt_context *ctx);   /* ctx may be NULL: last rt_create failure         */
+int rt_api_version(void);
+
+/* ---- host-side helpers (no device needed) ------------------------------------------------ */
+
+/* The Camera constructor, camera.h:18-45 (double tan, float elsewhere). */
+void rt_camera_init(rt_camera *cam, const float position[3], const float dir[3], float fov_degrees,
+                    int32_t width, int32_t height);
+
+/* Scene generators shared by the CLI, the tests and the bench.
+ *   RT_SCENE_DEFAULT  InitScene, main.cpp:21-63 (6 objects)
+ *   RT_SCENE_GRID1K   32x32 spheres + 4 emitters + tiled plane (1029 objects)
+ *   RT_SCENE_GRID16K  128x128 reflective spheres + 8 emitters + tiled plane (16393 objects)
+ * Returns the object count; writes at most `cap` objects (call with cap = 0 to size).
+ * `frame`/`n_frames` select the camera of the GRID16K sweep; ignored elsewhere. */
+enum { RT_SCENE_DEFAULT = 0, RT_SCENE_GRID1K = 1, RT_SCENE_GRID16K = 2 };
+int32_t rt_make_scene(int32_t kind, int32_t width, int32_t height, int32_t frame, int32_t n_frames,
+                      rt_object *objs, int32_t cap, rt_camera *cam);
+
+/* Splits `height` rows into n contiguous bands of near-equal cost given per-row costs
+ * (cost == NULL: equal rows).  Writes n+1 boundaries to `bounds`. */
+int rt_split_bands(const float *row_cost, int32_t height, int32_t n, int32_t *bounds);
+
+/* BMP file exactly as WriteBitmap produces it (writebitmap.h:88-182) from Bitmap::pData-layout
+ * rgb8, with buffered rows instead of one fprintf per byte. */
+int rt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */

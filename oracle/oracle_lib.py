@@ -1,0 +1,78 @@
+"""ctypes wrapper of oracle/liboracle.so (and oracle/_ref/libref.so when present).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_PATH = os.path.join(_HERE, "liboracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libref.so")
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("primary_rays", "reflection_rays", "shadow_rays_pruned", "shadow_rays_verbatim",
+                 "calls", "hits", "lit", "nearest_tests", "shadow_tests", "sphere_tests",
+                 "sphere_accepts", "plane_tests", "plane_accepts")] + [("calls_by_depth", C.c_uint64 * 16)]
+
+
+def load_oracle():
+    if not os.path.exists(ORACLE_PATH):
+        raise ImportError(f"{ORACLE_PATH} missing: run `make -C oracle`")
+    return C.CDLL(ORACLE_PATH)
+
+
+def load_ref():
+    """The reference's own headers compiled in the build container; None when absent."""
+    if not os.path.exists(REF_PATH):
+        return None
+    return C.CDLL(REF_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_oracle()
+        _lib.orc_render.restype = None
+        _lib.orc_trace.restype = None
+        _lib.orc_trace_samples.restype = None
+    return _lib
+
+
+def render(objs, cam, params, verbatim=False, threads=1, want_rgb8=True, want_f32=True, want_stats=False):
+    """orc_render over full-image buffers; returns (rgb8 HxWx3, f32 HxWx4, stats dict|None)."""
+    h, w = params.height, params.width
+    rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 else None
+    f32 = np.zeros((h, w, 4), dtype=np.float32) if want_f32 else None
+    st = OrcStats() if want_stats else None
+    lib().orc_render(objs, C.c_int(len(objs)), C.byref(cam), C.byref(params), C.c_int(int(verbatim)),
+                     C.c_int(threads),
+                     rgb8.ctypes.data_as(C.c_void_p) if want_rgb8 else None,
+                     f32.ctypes.data_as(C.c_void_p) if want_f32 else None,
+                     C.byref(st) if want_stats else None)
+    sd = None
+    if want_stats:
+        sd = {n: getattr(st, n) for n, _ in OrcStats._fields_[:-1]}
+        sd["calls_by_depth"] = list(st.calls_by_depth)
+    return rgb8, f32, sd
+
+
+def trace_samples(objs, cam, max_depth, sxy):
+    sxy = np.ascontiguousarray(sxy, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((sxy.shape[0], 3), dtype=np.float32)
+    lib().orc_trace_samples(objs, C.c_int(len(objs)), C.byref(cam), C.c_int(max_depth),
+                            sxy.ctypes.data_as(C.c_void_p), C.c_int(sxy.shape[0]),
+                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def write_bmp(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    return lib().orc_write_bmp(os.fsencode(path), C.c_int(w), C.c_int(h), rgb8.ctypes.data_as(C.c_void_p))

@@ -1,0 +1,228 @@
+"""ctypes binding of the C ABI in include/rt_api.h (raytracer_amd/librt_amd.so).
+
+This is plumbing for the tests and bench.py: every call goes through the same exported symbols a
+C/C++ host would use.  There is no fallback: if the shared library is missing the import fails,
+and if no HIP device is usable ``Context()`` raises ``RtError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+RT_OK = 0
+RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_BUFFER_TOO_SMALL = -1, -2, -3, -4
+RT_ERR_NO_SCENE, RT_ERR_NO_FRAME, RT_ERR_LIMIT = -5, -6, -7
+RT_OBJ_SPHERE, RT_OBJ_TILED_PLANE = 0, 1
+RT_OUT_RGBA8, RT_OUT_F32X4 = 1, 2
+RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
+RT_MODE_EXACT, RT_MODE_FAST = 0, 1
+RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
+
+
+class Material(C.Structure):
+    """rt_material == struct Material (raytracer_cpp/sceneobjects.h:3-9)."""
+    _fields_ = [("albedo", C.c_float * 3), ("specular", C.c_float * 3),
+                ("reflectance", C.c_float), ("emissive", C.c_float * 3)]
+
+
+class Object(C.Structure):
+    """rt_object: POD flattening of Sphere / TiledPlane (sceneobjects.h:36-131)."""
+    _fields_ = [("type", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3),
+                ("radius", C.c_float), ("mat", Material), ("mat2", Material)]
+
+
+class Camera(C.Structure):
+    """rt_camera == the fields of struct Camera (raytracer_cpp/camera.h:6-16)."""
+    _fields_ = [("position", C.c_float * 3), ("view_direction", C.c_float * 3),
+                ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("aspect_ratio", C.c_float), ("half_angle", C.c_float),
+                ("image_width", C.c_float), ("image_height", C.c_float)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
+                ("spp", C.c_int32), ("sample_offsets", C.POINTER(C.c_float)),
+                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("outputs", C.c_int32),
+                ("mode", C.c_int32), ("collect_stats", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
+                 "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + [("kernel_ms", C.c_double)]
+
+
+EXPORTS = [
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_render", "rt_download_framebuffer",
+    "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_render_async",
+    "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
+    "rt_make_scene", "rt_split_bands", "rt_write_bmp",
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+            "(or __graft_entry__.build()). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float)
+    lib.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_destroy.restype = None
+    lib.rt_upload_scene.argtypes = [vp, C.POINTER(Object), i32, C.POINTER(Camera)]
+    lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
+    lib.rt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
+    lib.rt_sync.argtypes = [vp]
+    lib.rt_download_framebuffer.argtypes = [vp, vp, C.c_size_t, i32]
+    lib.rt_framebuffer_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.rt_bind_framebuffer.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_api_version.argtypes = []
+    lib.rt_camera_init.argtypes = [C.POINTER(Camera), f32p, f32p, C.c_float, i32, i32]
+    lib.rt_camera_init.restype = None
+    lib.rt_make_scene.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Object), i32, C.POINTER(Camera)]
+    lib.rt_make_scene.restype = i32
+    lib.rt_split_bands.argtypes = [f32p, i32, i32, C.POINTER(i32)]
+    lib.rt_write_bmp.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_uint8)]
+    return lib
+
+
+lib = _load()
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"rt_status {code}: {text}")
+        self.code = code
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_init(position, direction, fov, width, height):
+    """Camera::Camera (camera.h:18-45) through rt_camera_init."""
+    cam = Camera()
+    lib.rt_camera_init(C.byref(cam), _f3(position), _f3(direction), float(fov), int(width), int(height))
+    return cam
+
+
+def make_scene(kind, width, height, frame=0, n_frames=240):
+    """Returns (ctypes array of Object, Camera) from rt_make_scene."""
+    cam = Camera()
+    n = lib.rt_make_scene(kind, width, height, frame, n_frames, None, 0, None)
+    if n < 0:
+        raise RtError(n, "rt_make_scene")
+    objs = (Object * n)()
+    lib.rt_make_scene(kind, width, height, frame, n_frames, objs, n, C.byref(cam))
+    return objs, cam
+
+
+def split_bands(height, n, row_cost=None):
+    bounds = (C.c_int32 * (n + 1))()
+    cost = None
+    if row_cost is not None:
+        arr = np.ascontiguousarray(row_cost, dtype=np.float32)
+        assert arr.shape == (height,)
+        cost = arr.ctypes.data_as(C.POINTER(C.c_float))
+    rc = lib.rt_split_bands(cost, height, n, bounds)
+    if rc:
+        raise RtError(rc, "rt_split_bands")
+    return list(bounds)
+
+
+def write_bmp(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    rc = lib.rt_write_bmp(os.fsencode(path), w, h, rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc:
+        raise RtError(rc, "rt_write_bmp")
+
+
+def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
+                  mode=RT_MODE_EXACT, stats=False):
+    p = RenderParams()
+    p.width, p.height, p.max_depth, p.spp = width, height, max_depth, spp
+    keep = None
+    if offsets is not None:
+        keep = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1)
+        assert keep.size == 2 * spp
+        p.sample_offsets = keep.ctypes.data_as(C.POINTER(C.c_float))
+    if rows is not None:
+        p.row_begin, p.row_end = rows
+    p.outputs, p.mode, p.collect_stats = outputs, mode, int(stats)
+    p._keep = keep  # keep the offsets array alive as long as the struct
+    return p
+
+
+class Context:
+    """rt_context: one device, one stream."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib.rt_create(C.byref(self._h), device)
+        if rc:
+            raise RtError(rc, lib.rt_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc:
+            raise RtError(rc, lib.rt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, objs, cam):
+        self._check(lib.rt_upload_scene(self._h, objs, len(objs), C.byref(cam)))
+
+    def render(self, params, wait=True):
+        fn = lib.rt_render if wait else lib.rt_render_async
+        self._check(fn(self._h, C.byref(params)))
+
+    def sync(self):
+        self._check(lib.rt_sync(self._h))
+
+    def stream(self):
+        s = C.c_void_p()
+        self._check(lib.rt_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def bind_framebuffer(self, plane, ptr, nbytes):
+        self._check(lib.rt_bind_framebuffer(self._h, plane, C.c_void_p(ptr), nbytes))
+
+    def device_ptr(self, plane):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(lib.rt_framebuffer_device_ptr(self._h, plane, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def download(self, fmt, width, rows):
+        if fmt == RT_FMT_F32X4:
+            out = np.empty((rows, width, 4), dtype=np.float32)
+        elif fmt == RT_FMT_RGBA8:
+            out = np.empty((rows, width, 4), dtype=np.uint8)
+        elif fmt == RT_FMT_RGB8:
+            out = np.empty((rows, width, 3), dtype=np.uint8)
+        else:
+            stride = width * 3 + (4 - (width * 3) % 4) % 4
+            out = np.empty((rows, stride), dtype=np.uint8)
+        self._check(lib.rt_download_framebuffer(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes, fmt))
+        return out
+
+    def stats(self):
+        st = Stats()
+        self._check(lib.rt_get_stats(self._h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in Stats._fields_}

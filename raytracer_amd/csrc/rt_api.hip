@@ -1,0 +1,419 @@
+// rt_api.hip -- device half of the C ABI (include/rt_api.h): context, scene upload, render,
+// framebuffer download.  One context = one HIP device = one stream.  There is no CPU fallback:
+// every entry point that needs the device fails with an rt_status when HIP is unusable.
+#include "rt_device.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    char err[512] = {0};
+
+    // scene
+    void *scene_blob = nullptr;       // one allocation holding geom | sph_id | planes | mats | emit
+    size_t scene_blob_bytes = 0;
+    RtSceneDev scene = {};
+    rt_camera cam = {};
+    bool have_scene = false;
+
+    // frame
+    void *own_plane[2] = {nullptr, nullptr};    // [0] rgba8, [1] f32x4 (library-owned)
+    size_t own_bytes[2] = {0, 0};
+    void *bound_plane[2] = {nullptr, nullptr};  // caller-owned (rt_bind_framebuffer)
+    size_t bound_bytes[2] = {0, 0};
+    void *cur_plane[2] = {nullptr, nullptr};    // planes of the last render
+    RtFrameDev frame = {};
+    bool have_frame = false;
+    int last_outputs = 0;
+
+    RtStatsDev *stats_dev = nullptr;
+    rt_stats stats = {};
+    bool stats_pending = false;
+    int lds_budget = 48 * 1024;
+};
+
+static char g_create_err[512] = "";
+
+static int fail(rt_context *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+static const float kRefPattern[8] = {0.1f, 0.2f, 0.6f, 0.5f, 0.8f, 0.7f, 0.2f, 0.8f};  // main.cpp:202
+
+static bool emissive_nonzero(const rt_material &m)
+{
+    return !(m.emissive[0] == 0.0f && m.emissive[1] == 0.0f && m.emissive[2] == 0.0f);  // main.cpp:131
+}
+
+extern "C" {
+
+int rt_create(rt_context **out, int device_id)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", device_id, n);
+    rt_context *ctx = new rt_context();
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->stats_dev, sizeof(RtStatsDev));
+    if (e != hipSuccess) {
+        fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e));
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scene_blob) (void)hipFree(ctx->scene_blob);
+    for (int i = 0; i < 2; i++)
+        if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
+    if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rt_last_error(rt_context *ctx) { return ctx ? ctx->err : g_create_err; }
+
+int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_camera *cam)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!objs || n <= 0 || !cam) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: objs/cam NULL or n <= 0");
+    if (n > (1 << 22)) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %d objects > limit %d", n, 1 << 22);
+
+    std::vector<float4> geom;
+    std::vector<int32_t> sph_id;
+    std::vector<RtPlaneDev> planes;
+    std::vector<rt_material> mats((size_t)2 * n);
+    std::vector<RtEmitterDev> emit;
+    for (int32_t k = 0; k < n; k++) {
+        const rt_object &o = objs[k];
+        mats[2 * (size_t)k] = o.mat;
+        mats[2 * (size_t)k + 1] = o.mat2;
+        bool emits;
+        int32_t slot = -1;
+        if (o.type == RT_OBJ_SPHERE) {
+            slot = (int32_t)geom.size();
+            geom.push_back(make_float4(o.a[0], o.a[1], o.a[2], o.radius * o.radius));  // sceneobjects.h:71
+            sph_id.push_back(k);
+            mats[2 * (size_t)k + 1] = o.mat;
+            emits = emissive_nonzero(o.mat);
+        } else if (o.type == RT_OBJ_TILED_PLANE) {
+            RtPlaneDev p = {o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], k, 0};
+            planes.push_back(p);
+            emits = emissive_nonzero(o.mat) || emissive_nonzero(o.mat2);
+        } else {
+            return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: object %d has unknown type %d", k, o.type);
+        }
+        if (emits) {
+            RtEmitterDev e = {o.a[0], o.a[1], o.a[2], k, o.type == RT_OBJ_TILED_PLANE ? 1 : 0, slot, 0, 0};
+            emit.push_back(e);
+        }
+    }
+    if (planes.size() > RT_MAX_PLANES)
+        return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %zu planes > limit %d", planes.size(), RT_MAX_PLANES);
+    if (emit.size() > RT_MAX_EMITTERS)
+        return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %zu emissive objects > limit %d", emit.size(), RT_MAX_EMITTERS);
+
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off_geom = 0;
+    size_t off_id = align(off_geom + geom.size() * sizeof(float4));
+    size_t off_planes = align(off_id + sph_id.size() * sizeof(int32_t));
+    size_t off_mats = align(off_planes + planes.size() * sizeof(RtPlaneDev));
+    size_t off_emit = align(off_mats + mats.size() * sizeof(rt_material));
+    size_t total = align(off_emit + emit.size() * sizeof(RtEmitterDev)) + 256;
+
+    std::vector<uint8_t> blob(total, 0);
+    if (!geom.empty()) memcpy(blob.data() + off_geom, geom.data(), geom.size() * sizeof(float4));
+    if (!sph_id.empty()) memcpy(blob.data() + off_id, sph_id.data(), sph_id.size() * sizeof(int32_t));
+    if (!planes.empty()) memcpy(blob.data() + off_planes, planes.data(), planes.size() * sizeof(RtPlaneDev));
+    memcpy(blob.data() + off_mats, mats.data(), mats.size() * sizeof(rt_material));
+    if (!emit.empty()) memcpy(blob.data() + off_emit, emit.data(), emit.size() * sizeof(RtEmitterDev));
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // a render may still read the old scene
+    if (total > ctx->scene_blob_bytes) {
+        if (ctx->scene_blob) RT_HIP(ctx, hipFree(ctx->scene_blob));
+        ctx->scene_blob = nullptr;
+        ctx->scene_blob_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->scene_blob, total));
+        ctx->scene_blob_bytes = total;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scene_blob, blob.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // blob is a stack-lifetime host buffer
+
+    uint8_t *base = (uint8_t *)ctx->scene_blob;
+    ctx->scene.geom = (const float4 *)(base + off_geom);
+    ctx->scene.sph_id = (const int32_t *)(base + off_id);
+    ctx->scene.planes = (const RtPlaneDev *)(base + off_planes);
+    ctx->scene.mats = (const rt_material *)(base + off_mats);
+    ctx->scene.emit = (const RtEmitterDev *)(base + off_emit);
+    ctx->scene.n_spheres = (int32_t)geom.size();
+    ctx->scene.n_planes = (int32_t)planes.size();
+    ctx->scene.n_objects = n;
+    ctx->scene.n_emit = (int32_t)emit.size();
+    ctx->cam = *cam;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+static int ensure_plane(rt_context *ctx, int plane, size_t bytes)
+{
+    if (ctx->bound_plane[plane]) {
+        if (ctx->bound_bytes[plane] < bytes)
+            return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "bound framebuffer plane %d holds %zu bytes, render needs %zu",
+                        plane, ctx->bound_bytes[plane], bytes);
+        ctx->cur_plane[plane] = ctx->bound_plane[plane];
+        return RT_OK;
+    }
+    if (ctx->own_bytes[plane] < bytes) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->own_plane[plane]) RT_HIP(ctx, hipFree(ctx->own_plane[plane]));
+        ctx->own_plane[plane] = nullptr;
+        ctx->own_bytes[plane] = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->own_plane[plane], bytes));
+        ctx->own_bytes[plane] = bytes;
+    }
+    ctx->cur_plane[plane] = ctx->own_plane[plane];
+    return RT_OK;
+}
+
+int rt_render_async(rt_context *ctx, const rt_render_params *p)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: params NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+    if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad image size %dx%d", p->width, p->height);
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_LEVELS - 1)
+        return fail(ctx, RT_ERR_LIMIT, "rt_render: max_depth %d outside [0,%d]", p->max_depth, RT_MAX_LEVELS - 1);
+    if (p->spp < 1 || p->spp > RT_MAX_SPP)
+        return fail(ctx, RT_ERR_LIMIT, "rt_render: spp %d outside [1,%d]", p->spp, RT_MAX_SPP);
+    if (!p->sample_offsets && p->spp != 1 && p->spp != 4)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: spp %d needs sample_offsets (the reference pattern covers 1 and 4)", p->spp);
+    int y0 = p->row_begin, y1 = p->row_end;
+    if (y0 == 0 && y1 == 0) y1 = p->height;
+    if (y0 < 0 || y1 > p->height || y0 > y1)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad row range [%d,%d) for height %d", y0, y1, p->height);
+    if (p->mode != RT_MODE_EXACT && p->mode != RT_MODE_FAST)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", p->mode);
+    int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
+    if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown output flags 0x%x", outputs);
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)p->width * (size_t)(y1 - y0);
+    ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
+    if (outputs & RT_OUT_RGBA8) {
+        int rc = ensure_plane(ctx, 0, px * 4 ? px * 4 : 4);
+        if (rc) return rc;
+    }
+    if (outputs & RT_OUT_F32X4) {
+        int rc = ensure_plane(ctx, 1, px * 16 ? px * 16 : 16);
+        if (rc) return rc;
+    }
+
+    RtFrameDev fr = {};
+    fr.rgba8 = (uint32_t *)ctx->cur_plane[0];
+    fr.f32x4 = (float4 *)ctx->cur_plane[1];
+    fr.width = p->width;
+    fr.height = p->height;
+    fr.row_begin = y0;
+    fr.row_end = y1;
+    fr.max_depth = p->max_depth;
+    fr.spp = p->spp;
+    fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
+    int cap = ctx->lds_budget / (int)sizeof(float4);
+    fr.chunk = ctx->scene.n_spheres < cap ? ctx->scene.n_spheres : cap;
+
+    RtSamples smp;
+    memset(&smp, 0, sizeof smp);
+    memcpy(smp.xy, p->sample_offsets ? p->sample_offsets : kRefPattern, sizeof(float) * 2 * (size_t)p->spp);
+
+    RtStatsDev *sdev = nullptr;
+    if (p->collect_stats) {
+        sdev = ctx->stats_dev;
+        RT_HIP(ctx, hipMemsetAsync(sdev, 0, sizeof(RtStatsDev), ctx->stream));
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (px > 0) {
+        // RT_MODE_FAST currently shares the exact kernel (a superset of its contract).
+        RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    ctx->frame = fr;
+    ctx->have_frame = true;
+    ctx->last_outputs = outputs;
+    ctx->timed = true;
+    ctx->stats_pending = p->collect_stats != 0;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.primary_rays = (uint64_t)px * (uint64_t)p->spp;
+    ctx->stats.n_objects = (uint64_t)ctx->scene.n_objects;
+    ctx->stats.n_emitters = (uint64_t)ctx->scene.n_emit;
+    return RT_OK;
+}
+
+int rt_sync(rt_context *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_context *ctx, const rt_render_params *p)
+{
+    int rc = rt_render_async(ctx, p);
+    if (rc) return rc;
+    return rt_sync(ctx);
+}
+
+int rt_get_stream(rt_context *ctx, void **out_stream)
+{
+    if (!ctx || !out_stream) return RT_ERR_INVALID_ARG;
+    *out_stream = (void *)ctx->stream;
+    return RT_OK;
+}
+
+int rt_bind_framebuffer(rt_context *ctx, int32_t plane, void *device_ptr, size_t bytes)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int idx = plane == RT_OUT_RGBA8 ? 0 : plane == RT_OUT_F32X4 ? 1 : -1;
+    if (idx < 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_framebuffer: plane must be RT_OUT_RGBA8 or RT_OUT_F32X4");
+    if (device_ptr && ((uintptr_t)device_ptr & 15))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_framebuffer: pointer must be 16-byte aligned");
+    ctx->bound_plane[idx] = device_ptr;
+    ctx->bound_bytes[idx] = device_ptr ? bytes : 0;
+    return RT_OK;
+}
+
+int rt_framebuffer_device_ptr(rt_context *ctx, int32_t plane, void **out_ptr, size_t *out_bytes)
+{
+    if (!ctx || !out_ptr) return RT_ERR_INVALID_ARG;
+    if (!ctx->have_frame) return fail(ctx, RT_ERR_NO_FRAME, "rt_framebuffer_device_ptr: nothing rendered yet");
+    int idx = plane == RT_OUT_RGBA8 ? 0 : plane == RT_OUT_F32X4 ? 1 : -1;
+    if (idx < 0 || !ctx->cur_plane[idx])
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_framebuffer_device_ptr: plane %d was not rendered", plane);
+    *out_ptr = ctx->cur_plane[idx];
+    if (out_bytes)
+        *out_bytes = (size_t)ctx->frame.width * (size_t)(ctx->frame.row_end - ctx->frame.row_begin) * (idx ? 16 : 4);
+    return RT_OK;
+}
+
+int rt_download_framebuffer(rt_context *ctx, void *dst, size_t dst_bytes, int32_t format)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!dst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_download_framebuffer: dst NULL");
+    if (!ctx->have_frame) return fail(ctx, RT_ERR_NO_FRAME, "rt_download_framebuffer: nothing rendered yet");
+    const RtFrameDev &fr = ctx->frame;
+    const size_t w = (size_t)fr.width, rows = (size_t)(fr.row_end - fr.row_begin), px = w * rows;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (format == RT_FMT_F32X4) {
+        if (!ctx->cur_plane[1]) return fail(ctx, RT_ERR_INVALID_ARG, "rt_download_framebuffer: F32X4 plane was not rendered");
+        if (dst_bytes < px * 16) return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_download_framebuffer: need %zu bytes, got %zu", px * 16, dst_bytes);
+        RT_HIP(ctx, hipMemcpyAsync(dst, ctx->cur_plane[1], px * 16, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    if (!ctx->cur_plane[0]) return fail(ctx, RT_ERR_INVALID_ARG, "rt_download_framebuffer: RGBA8 plane was not rendered");
+    if (format == RT_FMT_RGBA8) {
+        if (dst_bytes < px * 4) return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_download_framebuffer: need %zu bytes, got %zu", px * 4, dst_bytes);
+        RT_HIP(ctx, hipMemcpyAsync(dst, ctx->cur_plane[0], px * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    if (format != RT_FMT_RGB8 && format != RT_FMT_BMP_BODY)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_download_framebuffer: unknown format %d", format);
+    const size_t pad = format == RT_FMT_BMP_BODY ? (4 - (w * 3) % 4) % 4 : 0;
+    const size_t stride = w * 3 + pad, need = stride * rows;
+    if (dst_bytes < need) return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_download_framebuffer: need %zu bytes, got %zu", need, dst_bytes);
+    std::vector<uint32_t> tmp(px ? px : 1);
+    RT_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->cur_plane[0], px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t *out = (uint8_t *)dst;
+    for (size_t r = 0; r < rows; r++) {
+        const uint32_t *src = tmp.data() + r * w;
+        if (format == RT_FMT_RGB8) {                       // Bitmap::pData, writebitmap.h:67-70
+            uint8_t *o = out + r * stride;
+            for (size_t x = 0; x < w; x++) {
+                uint32_t v = src[x];
+                o[3 * x] = (uint8_t)v; o[3 * x + 1] = (uint8_t)(v >> 8); o[3 * x + 2] = (uint8_t)(v >> 16);
+            }
+        } else {                                           // writebitmap.h:161-178: bottom-up, b,g,r, padded
+            uint8_t *o = out + (rows - 1 - r) * stride;
+            for (size_t x = 0; x < w; x++) {
+                uint32_t v = src[x];
+                o[3 * x] = (uint8_t)(v >> 16); o[3 * x + 1] = (uint8_t)(v >> 8); o[3 * x + 2] = (uint8_t)v;
+            }
+            for (size_t k = 0; k < pad; k++) o[3 * w + k] = 0;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_get_stats(rt_context *ctx, rt_stats *out)
+{
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    if (!ctx->have_frame) return fail(ctx, RT_ERR_NO_FRAME, "rt_get_stats: nothing rendered yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->timed) {
+        float ms = 0.0f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->stats.kernel_ms = (double)ms;
+    }
+    if (ctx->stats_pending) {
+        RtStatsDev h;
+        RT_HIP(ctx, hipMemcpy(&h, ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost));
+        ctx->stats.reflection_rays = h.reflection;
+        ctx->stats.shadow_rays = h.shadow;
+        ctx->stats.hits = h.hits;
+        ctx->stats.lit = h.lit;
+        uint64_t rays = ctx->stats.primary_rays + h.reflection + h.shadow;
+        ctx->stats.sphere_tests = rays * (uint64_t)ctx->scene.n_spheres;
+        ctx->stats.plane_tests = rays * (uint64_t)ctx->scene.n_planes;
+        ctx->stats_pending = false;
+    }
+    *out = ctx->stats;
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+// rt_device.h -- device-side scene layout shared by the C-ABI implementation (rt_api.hip) and the
+// trace kernels (rt_kernels_*.hip).
+//
+// HBM layout of an uploaded scene (all arrays read-only during a render):
+//   geom   float4[n_spheres]   {cx, cy, cz, r*r} in LIST ORDER of the spheres; this is the only
+//                              array the intersection sweep streams (16 B per sphere, staged to LDS)
+//   sph_id int32[n_spheres]    list index of sphere i (ties and light order are by list index)
+//   planes RtPlaneDev[n_planes]
+//   mats   rt_material[2*n]    [2*k] = object k's material (plane: white), [2*k+1] = plane black
+//   emit   RtEmitterDev[n_emit] objects with a non-zero emissive material, in list order
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_api.h"
+
+#define RT_MAX_LEVELS 16      // path segments kept per sample: max_depth <= RT_MAX_LEVELS - 1
+#define RT_MAX_SPP 64
+#define RT_MAX_PLANES 16
+#define RT_MAX_EMITTERS 64
+
+struct RtPlaneDev {
+    float ox, oy, oz;
+    float nx, ny, nz;
+    int32_t id;           // list index
+    int32_t pad;
+};
+
+struct RtEmitterDev {
+    float cx, cy, cz;     // Sphere::center / Plane::origin: the point GetRayFrom aims at
+    int32_t id;           // list index
+    int32_t is_plane;
+    int32_t sphere_slot;  // index into geom[] when the emitter is a sphere, else -1
+    int32_t pad0, pad1;
+};
+
+struct RtSceneDev {
+    const float4 *geom;
+    const int32_t *sph_id;
+    const RtPlaneDev *planes;
+    const rt_material *mats;
+    const RtEmitterDev *emit;
+    int32_t n_spheres, n_planes, n_objects, n_emit;
+};
+
+struct RtFrameDev {
+    uint32_t *rgba8;      // band-relative: row (y - row_begin)
+    float4 *f32x4;
+    int32_t width, height;
+    int32_t row_begin, row_end;
+    int32_t max_depth, spp;
+    float inv_spp;
+    int32_t chunk;        // spheres staged to LDS per pass
+};
+
+struct RtStatsDev {
+    unsigned long long primary, reflection, shadow, hits, lit;
+};
+
+struct RtSamples {
+    float xy[2 * RT_MAX_SPP];
+};
+
+// kernel launchers (one translation unit per arithmetic contract)
+hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
+                                 const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
+
+#endif
