@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the trace loop on MI355X, with roofline and a CPU baseline.
+
+A step = one frame of the workload: the synthetic "grid-1024" scene (1024 jittered spheres + 4
+emissive spheres + tiled plane, SURVEY.md 8d config 4's scene) at 3840x2160, MAX_DEPTH 5, 1 sample
+per pixel (the metric's "4K depth 5").  With N ranks the frame is cut into N cost-balanced row
+bands (one per GPU) and the RGBA8 bands are gathered to rank 0 over RCCL: strong scaling.
+
+Rays = primary + reflection + shadow (one per hit x emissive object), counted once by a
+stats-enabled render outside the timed region.  Inputs (scene, camera) are resident in HBM before
+the timed region; the framebuffer stays on the device.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+FLOP_PER_SPHERE_TEST = 15       # 3 sub + 5 (dot) + 5 (dot) + mul + sub to the reject
+FLOP_PER_PLANE_TEST = 5
+
+
+def cpu_baseline(capi, width, height, depth, spp, kind):
+    """Times the CPU oracle (a port of the reference loop) on a bounded sample of the workload:
+    the same scene and camera at 1/2 resolution per axis."""
+    from oracle import oracle_lib
+    lw, lh = width // 2, height // 2
+    objs, cam = capi.make_scene(kind, lw, lh)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    p = capi.render_params(lw, lh, depth, spp)
+    t0 = time.perf_counter()
+    _, _, st = oracle_lib.render(objs, cam, p, threads=threads, want_rgb8=True, want_f32=False, want_stats=True)
+    dt = time.perf_counter() - t0
+    rays = st["primary_rays"] + st["reflection_rays"] + st["shadow_rays_pruned"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene/camera at {lw}x{lh} (1/4 of the pixels), depth {depth}, {spp} spp, "
+                      f"{rays} rays in {dt:.2f} s, emitter loop pruned to emissive objects"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import capi, multigpu
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trace loop has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
+    mode = capi.RT_MODE_EXACT if args.mode == "exact" else capi.RT_MODE_FAST
+    W, H = args.width, args.height
+    objs, cam = capi.make_scene(kind, W, H)
+    ctx = capi.Context(local)
+    ctx.upload_scene(objs, cam)
+
+    # band plan: identical on every rank (deterministic pre-pass), no communication
+    if world > 1:
+        cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
+        bounds = multigpu.plan_bands(cost, H, world)
+    else:
+        bounds = [0, H]
+    y0, y1 = bounds[rank], bounds[rank + 1]
+    max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
+    band = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)       # RGBA8 words
+    ctx.bind_framebuffer(capi.RT_OUT_RGBA8, band.data_ptr(), band.numel() * 4)
+    frame = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
+
+    # ray census of this rank's band (untimed)
+    ctx.render(capi.render_params(W, H, args.depth, args.spp, rows=(y0, y1), mode=mode, stats=True))
+    st = ctx.stats()
+    n_sph = sum(1 for o in objs if o.type == capi.RT_OBJ_SPHERE)
+    n_pl = len(objs) - n_sph
+    my_rays = st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
+    my_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
+
+    params = capi.render_params(W, H, args.depth, args.spp, rows=(y0, y1), mode=mode)
+
+    def step():
+        ctx.render(params)                                  # returns when the band is complete
+        if world > 1:
+            multigpu.gather_bands(band, bounds, rank, world, out=frame)
+        return ctx.stats()["kernel_ms"]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        kernel_ms += step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(my_rays), float(my_flop), kernel_ms / max(1, args.steps)],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, rays, flop, k_ms = mx[0].item(), sm[1].item(), sm[2].item(), mx[3].item()
+    else:
+        elapsed, rays, flop, k_ms = tot[0].item(), tot[1].item(), tot[2].item(), tot[3].item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the dominant (only) kernel on rank 0's launch: algorithmic FLOP / event time
+        k0_ms = kernel_ms / max(1, args.steps)
+        achieved = (my_flop / (k0_ms * 1e-3)) / 1e12 if k0_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 4K depth 5",
+            "value": rays * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene}: {len(objs)} objects ({n_sph} spheres, {st['n_emitters']} emissive), "
+                                   f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}",
+                       "rays_per_frame": int(rays), "bands": bounds,
+                       "parallelism": f"row-bands x{world}" + (" + RCCL gather" if world > 1 else "")},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": None,
+                         "kernel_ms": k0_ms,
+                         "algorithmic_flop_per_launch": int(my_flop),
+                         "note": "15 FLOP x rays x spheres + 5 FLOP x rays x planes (SURVEY 8d lower bound); "
+                                 "HBM traffic is the framebuffer only (4 B/px)"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,8 @@ typedef struct rt_camera {
 /* Output planes rt_render fills (bit flags). */
 enum {
     RT_OUT_RGBA8 = 1,   /* 4 B/px: r,g,b as PutPixel would store them (main.cpp:213-216), a = 255 */
-    RT_OUT_F32X4 = 2    /* 16 B/px: radiance after the 1/numSamples scale (main.cpp:210), w = 1   */
+    RT_OUT_F32X4 = 2    /* 16 B/px: radiance after the 1/numSamples scale (main.cpp:210); w = rays
+                           the pixel cost (primary + reflection + shadow): the band cost map  */
 };
 
 /* Download formats. */

@@ -307,18 +307,27 @@ static void *render_rows(void *arg)
     for (int y = y0 + j->offset; y < y1; y += j->stride) {                /* :196 */
         for (int x = 0; x < p->width; x++) {
             v3 color = v3_make(0.0f, 0.0f, 0.0f);
+            orc_stats px_st;
+            memset(&px_st, 0, sizeof px_st);
             for (int s = 0; s < p->spp; s++) {                            /* :203-209 */
                 float sx = (float)x + pat[2 * s], sy = (float)y + pat[2 * s + 1];
                 float d[3];
                 orc_world_ray(j->cam, sx, sy, d);
-                if (st) st->primary_rays++;
-                color = v3_add(color, trace(j->objs, j->n, cpos, v3_from(d), 0, p->max_depth, j->verbatim, st));
+                px_st.primary_rays++;
+                color = v3_add(color, trace(j->objs, j->n, cpos, v3_from(d), 0, p->max_depth, j->verbatim, &px_st));
             }
             color = v3_scale(color, 1.0f / (float)p->spp);                /* :210 */
             size_t idx = (size_t)p->width * (size_t)y + (size_t)x;
             if (j->f32x4) {
                 float *o = j->f32x4 + 4 * idx;
-                o[0] = color.x; o[1] = color.y; o[2] = color.z; o[3] = 1.0f;
+                /* w = rays this pixel cost: primary + reflection + pruned shadow rays */
+                o[0] = color.x; o[1] = color.y; o[2] = color.z;
+                o[3] = (float)(px_st.primary_rays + px_st.reflection_rays + px_st.shadow_rays_pruned);
+            }
+            if (st) {
+                const uint64_t *src = (const uint64_t *)&px_st;
+                uint64_t *dst = (uint64_t *)st;
+                for (size_t k = 0; k < sizeof(orc_stats) / sizeof(uint64_t); k++) dst[k] += src[k];
             }
             if (j->rgb8) {
                 v3 c = v3_scale(color, 255.0f);                           /* :213 */

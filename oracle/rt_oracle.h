@@ -47,7 +47,8 @@ int orc_checker_white(const float pos[3]);
 void orc_trace(const rt_object *objs, int n, const float orig[3], const float dir[3], int depth,
                int max_depth, int verbatim, float out[3], orc_stats *st);
 /* main.cpp:190-228.  Either output may be NULL.  rgb8: Bitmap::pData layout; f32x4: radiance after
- * the 1/spp scale, w = 1.  Rows [row_begin,row_end) are rendered into full-image-indexed buffers.
+ * the 1/spp scale, w = number of rays the pixel cost
+ * (primary + reflection + pruned shadow rays, all samples).  Rows [row_begin,row_end) are rendered into full-image-indexed buffers.
  * threads >= 1 interleaves rows like the reference's partitions. */
 void orc_render(const rt_object *objs, int n, const rt_camera *cam, const rt_render_params *p,
                 int verbatim, int threads, uint8_t *rgb8, float *f32x4, orc_stats *st);

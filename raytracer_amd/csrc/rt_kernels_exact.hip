@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void trace_exact_kernel(RtSceneDev sc, rt_c
                     nlev++;
                     float reflectance = sc.mats[mat].reflectance;
                     if (depth < fr.max_depth && reflectance > 0.0f) {        // main.cpp:103
-                        if (STATS) cnt.reflection++;
+                        cnt.reflection++;
                         ray.o = pos + refl * 0.001f;                         // main.cpp:108
                         ray.d = refl;
                     } else {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void trace_exact_kernel(RtSceneDev sc, rt_c
                 float dist; int slot, id;
                 find_nearest<CHUNKED>(sc, lds_geom, fr.chunk, on, sh, dist, slot, id);
                 if (on) {
-                    if (STATS) cnt.shadow++;
+                    cnt.shadow++;
                     // lit iff the nearest object along the shadow ray (lowest index on ties) is
                     // the emitter itself and its material there is emissive (main.cpp:119-157)
                     bool lit = (slot != INT_MIN) && id == em.id;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void trace_exact_kernel(RtSceneDev sc, rt_c
     if (in_image) {
         color = color * fr.inv_spp;                                          // main.cpp:210
         size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
-        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, 1.0f);
+        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, (float)(fr.spp + cnt.reflection + cnt.shadow));
         if (fr.rgba8)
             fr.rgba8[idx] = to_u8(color.x) | (to_u8(color.y) << 8) | (to_u8(color.z) << 16) | 0xff000000u;
     }
