@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,7 +18,7 @@ struct rt_context {
     char err[512] = {0};
 
     // scene
-    void *scene_blob = nullptr;       // one allocation holding geom | sph_id | planes | mats | emit
+    void *scene_blob = nullptr;       // one allocation holding pairs | geom | sph_id | planes | mats | emit
     size_t scene_blob_bytes = 0;
     RtSceneDev scene = {};
     rt_camera cam = {};
@@ -36,7 +37,8 @@ struct rt_context {
     RtStatsDev *stats_dev = nullptr;
     rt_stats stats = {};
     bool stats_pending = false;
-    int lds_budget = 48 * 1024;
+    int lds_budget = 40 * 1024;       // per workgroup: 4 workgroups of 4 waves fit a CU's 160 KiB
+    bool simple_kernel = false;       // RT_AMD_KERNEL=simple: the straight-transcription kernel (A/B)
 };
 
 static char g_create_err[512] = "";
@@ -81,6 +83,8 @@ int rt_create(rt_context **out, int device_id)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", device_id, n);
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
+    const char *kern = getenv("RT_AMD_KERNEL");
+    ctx->simple_kernel = kern && strcmp(kern, "simple") == 0;
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
@@ -152,8 +156,18 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (emit.size() > RT_MAX_EMITTERS)
         return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %zu emissive objects > limit %d", emit.size(), RT_MAX_EMITTERS);
 
+    std::vector<float4> pairs;
+    for (size_t i = 0; i < geom.size(); i += 2) {
+        const float4 g0 = geom[i];
+        // odd tail: a sphere at the origin with -r*r = +FLT_MAX, which no ray can hit
+        const float4 g1 = i + 1 < geom.size() ? geom[i + 1] : make_float4(0.0f, 0.0f, 0.0f, -3.402823466e+38f);
+        pairs.push_back(make_float4(g0.x, g1.x, g0.y, g1.y));
+        pairs.push_back(make_float4(g0.z, g1.z, -g0.w, -g1.w));
+    }
+
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t off_geom = 0;
+    size_t off_pairs = 0;
+    size_t off_geom = align(off_pairs + pairs.size() * sizeof(float4));
     size_t off_id = align(off_geom + geom.size() * sizeof(float4));
     size_t off_planes = align(off_id + sph_id.size() * sizeof(int32_t));
     size_t off_mats = align(off_planes + planes.size() * sizeof(RtPlaneDev));
@@ -161,6 +175,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     size_t total = align(off_emit + emit.size() * sizeof(RtEmitterDev)) + 256;
 
     std::vector<uint8_t> blob(total, 0);
+    if (!pairs.empty()) memcpy(blob.data() + off_pairs, pairs.data(), pairs.size() * sizeof(float4));
     if (!geom.empty()) memcpy(blob.data() + off_geom, geom.data(), geom.size() * sizeof(float4));
     if (!sph_id.empty()) memcpy(blob.data() + off_id, sph_id.data(), sph_id.size() * sizeof(int32_t));
     if (!planes.empty()) memcpy(blob.data() + off_planes, planes.data(), planes.size() * sizeof(RtPlaneDev));
@@ -180,6 +195,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // blob is a stack-lifetime host buffer
 
     uint8_t *base = (uint8_t *)ctx->scene_blob;
+    ctx->scene.pairs = (const float4 *)(base + off_pairs);
     ctx->scene.geom = (const float4 *)(base + off_geom);
     ctx->scene.sph_id = (const int32_t *)(base + off_id);
     ctx->scene.planes = (const RtPlaneDev *)(base + off_planes);
@@ -260,8 +276,14 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     fr.max_depth = p->max_depth;
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
-    int cap = ctx->lds_budget / (int)sizeof(float4);
-    fr.chunk = ctx->scene.n_spheres < cap ? ctx->scene.n_spheres : cap;
+    if (ctx->simple_kernel) {
+        int cap = ctx->lds_budget / (int)sizeof(float4);
+        fr.chunk = ctx->scene.n_spheres < cap ? ctx->scene.n_spheres : cap;
+    } else {
+        int cap = ctx->lds_budget / (4 * (int)sizeof(float4));    // geometry pair + camera-relative pair
+        int n_pairs = (ctx->scene.n_spheres + 1) / 2;
+        fr.chunk = n_pairs < cap ? n_pairs : cap;
+    }
 
     RtSamples smp;
     memset(&smp, 0, sizeof smp);
@@ -274,8 +296,10 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (px > 0) {
-        // RT_MODE_FAST currently shares the exact kernel (a superset of its contract).
-        RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
+        // One kernel serves both modes: it is bit-exact (RT_MODE_EXACT), which is a superset of
+        // RT_MODE_FAST's 1e-4 contract.
+        if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
+        else RT_HIP(ctx, rt_launch_trace_sweep(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 

@@ -2,8 +2,11 @@
 // trace kernels (rt_kernels_*.hip).
 //
 // HBM layout of an uploaded scene (all arrays read-only during a render):
-//   geom   float4[n_spheres]   {cx, cy, cz, r*r} in LIST ORDER of the spheres; this is the only
-//                              array the intersection sweep streams (16 B per sphere, staged to LDS)
+//   pairs  float4[2*ceil(n_spheres/2)]  spheres in LIST ORDER, two per 32-byte record:
+//                              {cx0,cx1,cy0,cy1} {cz0,cz1,-r0*r0,-r1*r1}; the only array the
+//                              intersection sweep streams (16 B per sphere, staged to LDS); an odd
+//                              tail is padded with a sphere nothing can hit (-r*r = +FLT_MAX)
+//   geom   float4[n_spheres]   {cx, cy, cz, r*r}: the same data unpaired (A/B kernel, hit lookups)
 //   sph_id int32[n_spheres]    list index of sphere i (ties and light order are by list index)
 //   planes RtPlaneDev[n_planes]
 //   mats   rt_material[2*n]    [2*k] = object k's material (plane: white), [2*k+1] = plane black
@@ -37,6 +40,7 @@ struct RtEmitterDev {
 };
 
 struct RtSceneDev {
+    const float4 *pairs;
     const float4 *geom;
     const int32_t *sph_id;
     const RtPlaneDev *planes;
@@ -52,7 +56,7 @@ struct RtFrameDev {
     int32_t row_begin, row_end;
     int32_t max_depth, spp;
     float inv_spp;
-    int32_t chunk;        // spheres staged to LDS per pass
+    int32_t chunk;        // LDS capacity per pass: sphere PAIRS (sweep kernel) / spheres (simple kernel)
 };
 
 struct RtStatsDev {
@@ -63,7 +67,9 @@ struct RtSamples {
     float xy[2 * RT_MAX_SPP];
 };
 
-// kernel launchers (one translation unit per arithmetic contract)
+// kernel launchers
+hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
+                                 const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
 hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
 

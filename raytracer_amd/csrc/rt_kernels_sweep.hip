@@ -1,0 +1,495 @@
+// rt_kernels_sweep.hip -- the production trace kernel for gfx950 (RT_MODE_EXACT and RT_MODE_FAST).
+// Compile with -ffp-contract=off (the explicit fma()s below are kept).
+//
+// Geometry: one wave64 = one 8x8 pixel tile, one 256-thread workgroup = four tiles sharing ONE LDS
+// copy of the sphere list.  Spheres are stored in PAIRS, 32 B per pair,
+//     A = {cx0, cx1, cy0, cy1}   B = {cz0, cz1, -r0^2, -r1^2}
+// so that a broadcast ds_read_b128 x2 feeds v_pk_*_f32 instructions that test two spheres at once.
+//
+// Per path segment a lane needs the nearest hit of 1 + E rays that all leave the same surface point
+// `pos` (the reflection ray and one shadow ray per emissive object, main.cpp:108 and :112-151).
+// They are swept TOGETHER, K <= 5 at a time, with a two-stage test per (ray, sphere):
+//
+//  1. conservative FILTER (the hot loop, packed FMA): with u = c - pos, uu = u.u, s = u.dn the
+//     squared distance from the sphere centre to the ray's LINE is uu - s^2 wherever on the line the
+//     origin sits, so u and uu are shared by all K rays and each ray costs 3 FMA + 1 FMA.  The
+//     sphere is a candidate when  uu*(1-2^-17) - r^2 - s^2 <= 2^-19 * (|pos|^2 + 2^-13); the two
+//     margins bound every rounding difference between this expression and the reference's
+//     dSquared (DESIGN.md "filter soundness"), so no sphere the reference accepts is ever dropped.
+//  2. EXACT test on candidates only (rare, divergent): glm::intersectRaySphere's arithmetic in the
+//     reference's operation order with the ray's true origin pos + dir*0.001.
+//
+// The result is bit-identical to the reference while the hot loop runs ~6 VALU lane-ops per test
+// instead of the ~17 of the straight transcription (rt_kernels_exact.hip, kept for A/B).
+//
+// The recursion of TraceRay (main.cpp:84-188) is unrolled without a stack: the hit chain is traced
+// forward (one combined sweep per segment also settles that segment's shadow rays as a bit mask),
+// then shading runs deepest-first in the reference's operation order.
+#include "rt_device.h"
+#include "rt_math.h"
+
+#include <float.h>
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kMaxK = 5;                       // rays swept together
+constexpr float kRelKeep = 1.0f - 0x1p-17f;    // filter: uu * (1 - 2^-17)
+constexpr float kAbsScale = 0x1p-19f;          // filter: 2^-19 * (|pos|^2 + 2^-13)
+constexpr float kAbsFloor = 0x1p-13f;
+
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// glm::intersectRaySphere, gtx/intersect.inl:105-123, via Sphere::Intersects (sceneobjects.h:69-73)
+__device__ __forceinline__ bool sphere_hit(float cx, float cy, float cz, float r2, V3 o, V3 dn, float &dist)
+{
+    V3 diff = v3(cx, cy, cz) - o;
+    float t0 = dot(diff, dn);
+    float dsq = dot(diff, diff) - t0 * t0;
+    if (dsq > r2) return false;
+    float t1 = sqrtf(r2 - dsq);
+    dist = t0 > t1 + FLT_EPSILON ? t0 - t1 : t0 + t1;
+    return dist > FLT_EPSILON;
+}
+
+// glm::intersectRayPlane, gtx/intersect.inl:7-24, via TiledPlane::Intersects (sceneobjects.h:127-130)
+__device__ __forceinline__ bool plane_hit(const RtPlaneDev &p, V3 o, V3 d, float &dist)
+{
+    V3 n = v3(p.nx, p.ny, p.nz);
+    float dn = dot(d, n);
+    if (dn < FLT_EPSILON) {
+        dist = dot(v3(p.ox, p.oy, p.oz) - o, n) / dn;
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ float filter_bound(V3 pos)
+{
+    return kAbsScale * (dot(pos, pos) + kAbsFloor);
+}
+
+template <int K>
+struct RaySet {
+    V3 o[K];        // true origin (exact test, plane test)
+    V3 d[K];        // direction as the reference passes it (plane test, pos = o + d*t)
+    V3 dn[K];       // normalize(d) (filter and exact sphere test)
+    bool act[K];
+    float best[K];
+    int slot[K];    // >= 0 sphere slot, INT_MIN none, < 0 plane: -1 - plane slot
+    int id[K];      // list index of the hit (filled by merge_planes)
+};
+
+// LDS image: [0, 2*cap) geometry pairs, [2*cap, 4*cap) camera-relative pairs (primary rays).
+template <bool CHUNKED>
+__device__ __forceinline__ void stage(const RtSceneDev &sc, float4 *lds, int cap, int base, int count,
+                                      bool with_cam, V3 cam)
+{
+    if (CHUNKED) __syncthreads();              // every wave is done with the previous chunk
+    for (int p = threadIdx.x; p < count; p += kBlock) {
+        float4 A = sc.pairs[2 * (base + p)], B = sc.pairs[2 * (base + p) + 1];
+        lds[2 * p] = A;
+        lds[2 * p + 1] = B;
+        if (with_cam) {
+            // u = c - cam, w = uu*(1-2^-17) - r^2 for both spheres of the pair
+            f2 ux = f2{A.x, A.y} - splat(cam.x), uy = f2{A.z, A.w} - splat(cam.y), uz = f2{B.x, B.y} - splat(cam.z);
+            f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
+            f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
+            lds[2 * cap + 2 * p] = make_float4(ux.x, ux.y, uy.x, uy.y);
+            lds[2 * cap + 2 * p + 1] = make_float4(uz.x, uz.y, w.x, w.y);
+        }
+    }
+    __syncthreads();
+}
+
+template <int K>
+__device__ __forceinline__ void exact_pair(RaySet<K> &r, const f2 (&q)[K], float bound, float4 A, float4 B, int slot0,
+                                           int n_spheres)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!r.act[k]) continue;
+        float dist;
+        if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) && r.best[k] > dist) {
+            r.best[k] = dist;
+            r.slot[k] = slot0;
+        }
+        if (q[k].y <= bound && slot0 + 1 < n_spheres &&
+            sphere_hit(A.y, A.w, B.y, -B.w, r.o[k], r.dn[k], dist) && r.best[k] > dist) {
+            r.best[k] = dist;
+            r.slot[k] = slot0 + 1;
+        }
+    }
+}
+
+// K rays leaving `pos` against every sphere.  FindNearestObject's order (main.cpp:65-82): spheres
+// are visited in list order with a strict '>' so the lowest index wins ties.
+template <int K, bool CHUNKED>
+__device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap, bool lane_on, V3 pos, RaySet<K> &r)
+{
+    f2 dx[K], dy[K], dz[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        r.best[k] = FLT_MAX;
+        r.slot[k] = INT_MIN;
+        V3 dn = r.act[k] ? r.dn[k] : v3(0.0f, 0.0f, 0.0f);
+        dx[k] = splat(dn.x); dy[k] = splat(dn.y); dz[k] = splat(dn.z);
+    }
+    const float bound = filter_bound(pos);
+    const f2 px = splat(pos.x), py = splat(pos.y), pz = splat(pos.z);
+    const int n_pairs = (sc.n_spheres + 1) >> 1;
+    for (int base = 0; base < n_pairs; base += cap) {
+        const int count = min(cap, n_pairs - base);
+        if (CHUNKED) stage<true>(sc, lds, cap, base, count, false, pos);
+        if (lane_on) {
+#pragma unroll 2
+            for (int p = 0; p < count; p++) {
+                const float4 A = lds[2 * p], B = lds[2 * p + 1];
+                const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
+                const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
+                const f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
+                f2 q[K];
+                float m = FLT_MAX;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const f2 s = pk_fma(uz, dz[k], pk_fma(uy, dy[k], ux * dx[k]));
+                    q[k] = pk_fma(-s, s, w);
+                    m = fminf(fminf(m, q[k].x), q[k].y);
+                }
+                if (m <= bound) exact_pair<K>(r, q, bound, A, B, 2 * (base + p), sc.n_spheres);
+            }
+        }
+    }
+}
+
+// Primary rays: every lane's origin is the camera, so u and w come precomputed from LDS.
+template <bool CHUNKED>
+__device__ __forceinline__ void sweep_primary(const RtSceneDev &sc, float4 *lds, int cap, bool lane_on, V3 cam,
+                                              RaySet<1> &r)
+{
+    r.best[0] = FLT_MAX;
+    r.slot[0] = INT_MIN;
+    const f2 dx = splat(r.dn[0].x), dy = splat(r.dn[0].y), dz = splat(r.dn[0].z);
+    const float bound = filter_bound(cam);
+    const int n_pairs = (sc.n_spheres + 1) >> 1;
+    for (int base = 0; base < n_pairs; base += cap) {
+        const int count = min(cap, n_pairs - base);
+        if (CHUNKED) stage<true>(sc, lds, cap, base, count, true, cam);
+        if (lane_on) {
+#pragma unroll 4
+            for (int p = 0; p < count; p++) {
+                const float4 U = lds[2 * cap + 2 * p], W = lds[2 * cap + 2 * p + 1];
+                const f2 s = pk_fma(f2{W.x, W.y}, dz, pk_fma(f2{U.z, U.w}, dy, f2{U.x, U.y} * dx));
+                f2 q[1];
+                q[0] = pk_fma(-s, s, f2{W.z, W.w});
+                if (fminf(q[0].x, q[0].y) <= bound)
+                    exact_pair<1>(r, q, bound, lds[2 * p], lds[2 * p + 1], 2 * (base + p), sc.n_spheres);
+            }
+        }
+    }
+}
+
+// Planes are few: the reference's own arithmetic per ray, merged with an explicit
+// (distance, list index) comparison, which is what the in-order strict '>' sweep amounts to.
+template <int K>
+__device__ __forceinline__ void merge_planes(const RtSceneDev &sc, bool lane_on, RaySet<K> &r)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        r.id[k] = -1;
+        if (!lane_on || !r.act[k]) continue;
+        if (r.slot[k] >= 0) r.id[k] = sc.sph_id[r.slot[k]];
+        for (int j = 0; j < sc.n_planes; j++) {
+            const RtPlaneDev p = sc.planes[j];
+            float dist;
+            if (plane_hit(p, r.o[k], r.d[k], dist)) {
+                if (r.best[k] > dist || (r.best[k] == dist && r.id[k] >= 0 && p.id < r.id[k])) {
+                    r.best[k] = dist;
+                    r.slot[k] = -1 - j;
+                    r.id[k] = p.id;
+                }
+            }
+        }
+    }
+}
+
+template <bool CHUNKED>
+__device__ __forceinline__ bool block_any(bool v)
+{
+    if (CHUNKED) return __syncthreads_or(v) != 0;
+    return __any(v) != 0;
+}
+
+struct Segment {          // what the next level needs from the sweep that found it
+    V3 o, d;              // the ray that produced the hit
+    float dist;
+    int slot, id;
+};
+
+// Sweeps `ne` shadow rays (emitters e0 .. e0+ne-1) and, when WITH_REFL, the reflection ray in slot 0.
+template <int K, bool WITH_REFL, bool CHUNKED>
+__device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos, V3 refl,
+                                            bool want_refl, int e0, unsigned long long &lit,
+                                            unsigned long long &alt, Segment &next, bool &next_hit)
+{
+    RaySet<K> r;
+    constexpr int kFirst = WITH_REFL ? 1 : 0;
+    if (WITH_REFL) {
+        r.o[0] = pos + refl * 0.001f;                                    // main.cpp:108
+        r.d[0] = refl;
+        r.dn[0] = normalize(refl);                                       // sceneobjects.h:71
+        r.act[0] = want_refl;
+    }
+#pragma unroll
+    for (int k = kFirst; k < K; k++) {
+        const RtEmitterDev em = sc.emit[e0 + k - kFirst];
+        const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);       // GetRayFrom, main.cpp:114
+        r.o[k] = pos + edir * 0.001f;                                    // main.cpp:121
+        r.d[k] = edir;
+        r.dn[k] = normalize(edir);
+        r.act[k] = on;
+    }
+    sweep<K, CHUNKED>(sc, lds, cap, on, pos, r);
+    merge_planes<K>(sc, on, r);
+    if (on) {
+#pragma unroll
+        for (int k = kFirst; k < K; k++) {
+            // lit iff the nearest object along the shadow ray (lowest index on ties) is the emitter
+            // itself and its material at that point is emissive (main.cpp:119-157)
+            const int e = e0 + k - kFirst;
+            const RtEmitterDev em = sc.emit[e];
+            bool is_lit = r.slot[k] != INT_MIN && r.id[k] == em.id;
+            if (is_lit && em.is_plane) {
+                const bool white = checker_white(pos + r.d[k] * r.best[k]);        // main.cpp:130
+                const rt_material pm = sc.mats[2 * em.id + (white ? 0 : 1)];
+                is_lit = !(pm.emissive[0] == 0.0f && pm.emissive[1] == 0.0f && pm.emissive[2] == 0.0f);
+                if (!white) alt |= 1ull << e;
+            }
+            if (is_lit) lit |= 1ull << e;
+        }
+        if (WITH_REFL && want_refl) {
+            next_hit = r.slot[0] != INT_MIN;
+            next.o = r.o[0];
+            next.d = r.d[0];
+            next.dist = r.best[0];
+            next.slot = r.slot[0];
+            next.id = r.id[0];
+        }
+    }
+}
+
+template <bool WITH_REFL, bool CHUNKED>
+__device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos,
+                                              V3 refl, bool want_refl, int e0, unsigned long long &lit,
+                                              unsigned long long &alt, Segment &next, bool &next_hit)
+{
+    switch (k_total) {       // uniform across the workgroup
+    case 1: trace_group<1, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    case 2: trace_group<2, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    case 3: trace_group<3, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    case 4: trace_group<4, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    default: trace_group<5, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    }
+}
+
+template <bool CHUNKED, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
+                                                             RtStatsDev *stats)
+{
+    extern __shared__ float4 lds[];
+    const int cap = fr.chunk;                         // pairs resident in LDS
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tiles_x = (fr.width + 7) >> 3;
+    const int rows = fr.row_end - fr.row_begin;
+    const int tiles_y = (rows + 7) >> 3;
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int yr = ty * 8 + (lane >> 3);
+    const int y = fr.row_begin + yr;
+    const bool in_image = (tile < tiles_x * tiles_y) && x < fr.width && yr < rows;
+
+    const V3 cam_pos = v3(cam.position[0], cam.position[1], cam.position[2]);
+    const V3 cam_view = v3(cam.view_direction[0], cam.view_direction[1], cam.view_direction[2]);
+    const V3 cam_right = v3(cam.right[0], cam.right[1], cam.right[2]);
+    const V3 cam_up = v3(cam.up[0], cam.up[1], cam.up[2]);
+
+    if (!CHUNKED) stage<false>(sc, lds, cap, 0, (sc.n_spheres + 1) >> 1, true, cam_pos);
+
+    // one record per path segment, read back deepest-first (runtime-indexed -> private memory)
+    float rec_pos[RT_MAX_LEVELS][3], rec_n[RT_MAX_LEVELS][3], rec_r[RT_MAX_LEVELS][3];
+    int rec_mat[RT_MAX_LEVELS];
+    unsigned long long rec_lit[RT_MAX_LEVELS], rec_alt[RT_MAX_LEVELS];
+
+    unsigned n_refl = 0, n_shadow = 0, n_hits = 0, n_lit = 0;
+    V3 color = v3(0.0f, 0.0f, 0.0f);
+
+    for (int s = 0; s < fr.spp; s++) {                                       // main.cpp:203
+        Segment seg;
+        bool alive;
+        {
+            // Camera::GetWorldRay, camera.h:48-62
+            float sx = (float)x + smp.xy[2 * s], sy = (float)y + smp.xy[2 * s + 1];   // main.cpp:205
+            float px = ((sx * 2.0f) / cam.image_width) - 1.0f;
+            float py = ((sy * 2.0f) / cam.image_height) - 1.0f;
+            V3 d = cam_view;
+            d = d + cam_right * (cam.half_angle * cam.aspect_ratio * px);
+            d = d - cam_up * (cam.half_angle * py);
+            RaySet<1> r;
+            r.o[0] = cam_pos;
+            r.d[0] = normalize(d);
+            r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
+            r.act[0] = in_image;
+            sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
+            merge_planes<1>(sc, in_image, r);
+            seg.o = r.o[0]; seg.d = r.d[0]; seg.dist = r.best[0]; seg.slot = r.slot[0]; seg.id = r.id[0];
+            alive = in_image && r.slot[0] != INT_MIN;
+        }
+        bool miss_tail = in_image && !alive;                                 // main.cpp:90-93
+        int nlev = 0;
+
+        // ---- forward: hit chain + shadow masks ----
+        for (int depth = 0; depth <= fr.max_depth; depth++) {
+            if (!block_any<CHUNKED>(alive)) break;
+            V3 pos = cam_pos, n = v3(0, 0, 0), refl = n;
+            bool want_refl = false;
+            if (alive) {
+                if (STATS) n_hits++;
+                pos = seg.o + seg.d * seg.dist;                              // main.cpp:94
+                int mat;
+                if (seg.slot >= 0) {
+                    const float4 A = sc.pairs[2 * (seg.slot >> 1)], B = sc.pairs[2 * (seg.slot >> 1) + 1];
+                    const V3 c = (seg.slot & 1) ? v3(A.y, A.w, B.y) : v3(A.x, A.z, B.x);
+                    n = normalize(pos - c);                                  // sceneobjects.h:59-62
+                    mat = 2 * seg.id;
+                } else {
+                    const RtPlaneDev p = sc.planes[-1 - seg.slot];
+                    n = v3(p.nx, p.ny, p.nz);                                // sceneobjects.h:117-120
+                    mat = 2 * seg.id + (checker_white(pos) ? 0 : 1);         // sceneobjects.h:106-115
+                }
+                refl = normalize(reflect(seg.d, n));                         // main.cpp:100
+                rec_pos[nlev][0] = pos.x; rec_pos[nlev][1] = pos.y; rec_pos[nlev][2] = pos.z;
+                rec_n[nlev][0] = n.x; rec_n[nlev][1] = n.y; rec_n[nlev][2] = n.z;
+                rec_r[nlev][0] = refl.x; rec_r[nlev][1] = refl.y; rec_r[nlev][2] = refl.z;
+                rec_mat[nlev] = mat;
+                want_refl = depth < fr.max_depth && sc.mats[mat].reflectance > 0.0f;   // main.cpp:103
+                if (want_refl) n_refl++;
+                n_shadow += sc.n_emit;
+            }
+            unsigned long long lit = 0, alt = 0;
+            Segment next = seg;
+            bool next_hit = false;
+            const bool any_refl = block_any<CHUNKED>(want_refl);
+            int e0 = 0;
+            if (any_refl) {
+                const int ne = min(sc.n_emit, kMaxK - 1);
+                trace_group_k<true, CHUNKED>(1 + ne, sc, lds, cap, alive, pos, refl, want_refl, 0, lit, alt, next, next_hit);
+                e0 = ne;
+            }
+            while (e0 < sc.n_emit) {
+                const int ne = min(sc.n_emit - e0, kMaxK);
+                trace_group_k<false, CHUNKED>(ne, sc, lds, cap, alive, pos, refl, false, e0, lit, alt, next, next_hit);
+                e0 += ne;
+            }
+            if (alive) {
+                rec_lit[nlev] = lit;
+                rec_alt[nlev] = alt;
+                nlev++;
+                if (want_refl) {
+                    seg = next;
+                    alive = next_hit;
+                    miss_tail = !next_hit;
+                } else {
+                    alive = false;
+                }
+            }
+        }
+
+        // ---- backward: shade deepest segment first (main.cpp:109-187) ----
+        V3 child = v3(0.1f, 0.1f, 0.1f);           // what a missing ray returns (main.cpp:92)
+        bool has_child = miss_tail;
+        for (int lev = nlev - 1; lev >= 0; lev--) {
+            const V3 pos = v3(rec_pos[lev][0], rec_pos[lev][1], rec_pos[lev][2]);
+            const V3 n = v3(rec_n[lev][0], rec_n[lev][1], rec_n[lev][2]);
+            const V3 refl = v3(rec_r[lev][0], rec_r[lev][1], rec_r[lev][2]);
+            const rt_material m = sc.mats[rec_mat[lev]];
+            const unsigned long long lit = rec_lit[lev], alt = rec_alt[lev];
+            V3 out = v3(0.0f, 0.0f, 0.0f);
+            if (has_child) out = child * m.reflectance;                      // main.cpp:109
+            for (int e = 0; e < sc.n_emit; e++) {                            // main.cpp:112
+                if (!((lit >> e) & 1ull)) continue;
+                const RtEmitterDev em = sc.emit[e];
+                const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);    // main.cpp:114
+                float diffuse = dot(n, edir);                                // main.cpp:162
+                float spec = 0.0f;
+                if (diffuse > 0.0f) {
+                    spec = dot(refl, edir);                                  // main.cpp:166
+                    if (spec > 0.0f) {
+                        spec = pow10_like_libm(spec);                        // main.cpp:169
+                        spec = 0.0f < spec ? spec : 0.0f;                    // main.cpp:170
+                    } else {
+                        spec = 0.0f;
+                    }
+                } else {
+                    diffuse = 0.0f;
+                }
+                if (STATS) n_lit++;
+                const float *ee = sc.mats[2 * em.id + (int)((alt >> e) & 1ull)].emissive;
+                const V3 l = (v3(ee[0], ee[1], ee[2]) * v3(m.albedo[0], m.albedo[1], m.albedo[2])) * diffuse +
+                             v3(m.specular[0], m.specular[1], m.specular[2]) * spec;   // main.cpp:183
+                out = out + l;
+            }
+            out = out * (1.f - m.reflectance);                               // main.cpp:185
+            out = out + v3(m.emissive[0], m.emissive[1], m.emissive[2]);     // main.cpp:186
+            child = out;
+            has_child = true;
+        }
+        if (in_image) color = color + child;                                 // main.cpp:208
+    }
+
+    if (in_image) {
+        color = color * fr.inv_spp;                                          // main.cpp:210
+        const size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
+        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, (float)(fr.spp + n_refl + n_shadow));
+        if (fr.rgba8)
+            fr.rgba8[idx] = to_u8(color.x) | (to_u8(color.y) << 8) | (to_u8(color.z) << 16) | 0xff000000u;
+    }
+
+    if (STATS) {
+        unsigned v[4] = {n_refl, n_shadow, n_hits, n_lit};
+        unsigned long long *dst[4] = {&stats->reflection, &stats->shadow, &stats->hits, &stats->lit};
+        for (int k = 0; k < 4; k++) {
+            unsigned t = in_image ? v[k] : 0u;
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0 && t) atomicAdd(dst[k], (unsigned long long)t);
+        }
+    }
+}
+
+} // namespace
+
+hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
+                                 const RtSamples &samples, RtStatsDev *stats, hipStream_t stream)
+{
+    const int rows = frame.row_end - frame.row_begin;
+    const int tiles = ((frame.width + 7) / 8) * ((rows + 7) / 8);
+    if (tiles <= 0) return hipSuccess;
+    const dim3 grid((tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+    const int n_pairs = (scene.n_spheres + 1) / 2;
+    const bool chunked = frame.chunk < n_pairs;
+    const size_t lds_bytes = (size_t)(frame.chunk > 0 ? frame.chunk : 1) * 4 * sizeof(float4);
+    if (chunked) {
+        if (stats) hipLaunchKernelGGL((trace_sweep_kernel<true, true>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+        else hipLaunchKernelGGL((trace_sweep_kernel<true, false>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+    } else {
+        if (stats) hipLaunchKernelGGL((trace_sweep_kernel<false, true>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+        else hipLaunchKernelGGL((trace_sweep_kernel<false, false>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+    }
+    return hipGetLastError();
+}

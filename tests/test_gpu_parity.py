@@ -28,3 +28,19 @@ def test_default_scene_exact(capi, oracle, gpu_ctx, spp):
     assert np.array_equal(f32_o.view(np.uint32), f32_g.view(np.uint32)), \
         f"{np.count_nonzero(f32_o.view(np.uint32) != f32_g.view(np.uint32))} radiance words differ"
     assert np.array_equal(rgb_o, rgb_g)
+
+
+def _assert_bits_equal(f32_o, f32_g, rgb_o, rgb_g):
+    bad = np.count_nonzero(f32_o.view(np.uint32) != f32_g.view(np.uint32))
+    assert bad == 0, f"{bad} radiance/ray-count words differ"
+    assert np.array_equal(rgb_o, rgb_g)
+
+
+@pytest.mark.parametrize("kind,w,h,depth", [(1, 640, 360, 5), (1, 320, 200, 8), (2, 256, 144, 5)])
+def test_grid_scenes_exact(capi, oracle, gpu_ctx, kind, w, h, depth):
+    """grid-1024 (LDS-resident) and grid-16k (LDS chunk streaming), odd tile edges included."""
+    objs, cam = capi.make_scene(kind, w, h, frame=17)
+    p = capi.render_params(w, h, depth, 1)
+    rgb_o, f32_o, _ = oracle.render(objs, cam, p, threads=16)
+    rgb_g, f32_g = _render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, 1)
+    _assert_bits_equal(f32_o, f32_g, rgb_o, rgb_g)
