@@ -34,9 +34,15 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kWavesPerBlock = 4;
+#ifndef RT_WAVES_PER_BLOCK
+#define RT_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RT_WAVES_PER_BLOCK;
 constexpr int kBlock = 64 * kWavesPerBlock;
 constexpr int kMaxK = 5;                       // rays swept together
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4
+#endif
 constexpr float kRelKeep = 1.0f - 0x1p-17f;    // filter: uu * (1 - 2^-17)
 constexpr float kAbsScale = 0x1p-19f;          // filter: 2^-19 * (|pos|^2 + 2^-13)
 constexpr float kAbsFloor = 0x1p-13f;
@@ -297,7 +303,7 @@ __device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc,
 }
 
 template <bool CHUNKED, bool STATS>
-__global__ __launch_bounds__(kBlock) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
     extern __shared__ float4 lds[];
