@@ -182,6 +182,25 @@ static inline int obj_may_emit(const rt_object *o)
     return o->type != RT_OBJ_SPHERE && emissive_nonzero(&o->mat2);
 }
 
+/* exported for the known-answer tests (tests/golden/vectors.json) */
+void orc_sphere_normal(const float c[3], const float pos[3], float out[3])
+{
+    v3 n = v3_normalize(v3_sub(v3_from(pos), v3_from(c)));             /* sceneobjects.h:59-62 */
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+void orc_ray_from(const float c[3], const float from[3], float out[3])
+{
+    v3 n = v3_normalize(v3_sub(v3_from(c), v3_from(from)));            /* sceneobjects.h:64-67 */
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+void orc_reflect_dir(const float i[3], const float n[3], float out[3])
+{
+    v3 r = v3_normalize(v3_reflect(v3_from(i), v3_from(n)));           /* main.cpp:100 */
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 /* ---- TraceRay, main.cpp:84-188 ------------------------------------------------------------- */
 
 static v3 trace(const rt_object *objs, int n, v3 orig, v3 dir, int depth, int max_depth, int verbatim, orc_stats *st)

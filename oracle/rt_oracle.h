@@ -42,6 +42,9 @@ int orc_sphere_intersects(const float center[3], float radius, const float orig[
 int orc_plane_intersects(const float porig[3], const float pnormal[3], const float orig[3], const float dir[3], float *dist);
 /* sceneobjects.h:106-115; returns 1 for white */
 int orc_checker_white(const float pos[3]);
+void orc_sphere_normal(const float c[3], const float pos[3], float out[3]);   /* sceneobjects.h:59-62 */
+void orc_ray_from(const float c[3], const float from[3], float out[3]);       /* sceneobjects.h:64-67 */
+void orc_reflect_dir(const float i[3], const float n[3], float out[3]);       /* main.cpp:100 */
 /* main.cpp:84-188.  verbatim != 0: every object is a candidate emitter (as written, O(N^2));
  * verbatim == 0: only objects with non-zero emissive (bit-identical). */
 void orc_trace(const rt_object *objs, int n, const float orig[3], const float dir[3], int depth,

@@ -1,0 +1,91 @@
+"""CPU tests of the C-ABI library itself: it loads, exports every symbol include/rt_api.h declares,
+its host-side helpers work without a device, and device entry points fail loudly (no CPU path)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rt_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_exports_match_header(capi):
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(capi.lib, name), f"librt_amd.so does not export {name}"
+    assert sorted(capi.EXPORTS) == declared
+    assert capi.lib.rt_api_version() == 1
+
+
+def test_no_oracle_in_product():
+    """The product must not reach into oracle/ (the checker) in any form."""
+    for base, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_device_fails_loudly(capi):
+    with pytest.raises(capi.RtError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.RT_ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+
+
+def test_null_arguments(capi):
+    assert capi.lib.rt_create(None, 0) == capi.RT_ERR_INVALID_ARG
+    assert capi.lib.rt_upload_scene(None, None, 0, None) == capi.RT_ERR_INVALID_ARG
+    assert capi.lib.rt_render(None, None) == capi.RT_ERR_INVALID_ARG
+    assert capi.lib.rt_download_framebuffer(None, None, 0, 0) == capi.RT_ERR_INVALID_ARG
+    capi.lib.rt_destroy(None)     # must be a no-op
+
+
+def test_default_scene_is_initscene(capi):
+    """InitScene, raytracer_cpp/main.cpp:21-63."""
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, 1024, 768)
+    assert len(objs) == 6
+    assert [o.type for o in objs] == [0, 0, 0, 0, 0, 1]
+    assert [round(o.radius, 3) for o in objs[:5]] == [2.0, 1.0, 0.5, 0.8, 0.4]
+    assert list(objs[3].mat.emissive) == [1.0, 1.0, 0.0] and list(objs[4].mat.emissive) == [1.0, 1.0, 1.0]
+    assert all(list(o.mat.emissive) == [0.0, 0.0, 0.0] for o in objs[:3])
+    assert list(objs[4].a) == [np.float32(-10.8), np.float32(8.4), 10.0]
+    assert list(cam.position) == [0.0, 6.0, 8.0] and cam.image_width == 1024.0 and cam.image_height == 768.0
+
+
+def test_grid_scene_shapes(capi):
+    for kind, n, ne in ((capi.RT_SCENE_GRID1K, 1029, 4), (capi.RT_SCENE_GRID16K, 16393, 8)):
+        objs, _ = capi.make_scene(kind, 640, 360, frame=3)
+        assert len(objs) == n
+        assert objs[n - 1].type == capi.RT_OBJ_TILED_PLANE
+        assert sum(1 for o in objs if any(o.mat.emissive)) == ne
+    assert capi.lib.rt_make_scene(99, 8, 8, 0, 1, None, 0, None) == capi.RT_ERR_INVALID_ARG
+
+
+def test_split_bands_properties(capi):
+    rng = np.random.default_rng(5)
+    for height, n in ((2160, 8), (2160, 1), (7, 8), (8, 8), (1080, 3), (33, 4)):
+        cost = rng.uniform(0.0, 5.0, height).astype(np.float32)
+        cost[: height // 3] *= 10
+        for c in (None, cost):
+            b = capi.split_bands(height, n, c)
+            assert b[0] == 0 and b[-1] == height and len(b) == n + 1
+            assert all(b[i] <= b[i + 1] for i in range(n))
+            if height >= n:
+                assert all(b[i] < b[i + 1] for i in range(n)), (height, n, b)
+        b = capi.split_bands(height, n, cost)
+        if height >= 20 * n:
+            band = [float(cost[b[i]:b[i + 1]].sum()) for i in range(n)]
+            assert max(band) <= float(cost.sum()) / n + 2 * float(cost.max()) + 1e-3
+    assert capi.split_bands(0, 2, None) == [0, 0, 0]
+    with pytest.raises(capi.RtError):
+        capi.split_bands(4, 0, None)

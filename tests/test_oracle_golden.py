@@ -1,0 +1,218 @@
+"""CPU tests: the oracle (oracle/rt_oracle.c) against the reference's own outputs.
+
+* tests/golden/survey_pins.json -- outputs of the verbatim raytracer_cpp program recorded by the
+  survey (BMP md5s, radiance values, camera basis, counters): pins the whole trace loop.
+* the other fixtures -- outputs of the reference's own headers compiled in the build container
+  (oracle/_ref, tests/gen_golden.py): pin every primitive bit for bit.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F3 = C.c_float * 3
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def fl(bits):
+    return np.asarray(bits, dtype=np.uint32).view(np.float32)
+
+
+def f3(bits):
+    return F3(*[float(x) for x in fl(bits)])
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float32).view(np.uint32)
+    b = np.asarray(b, dtype=np.float32).view(np.uint32)
+    return np.array_equal(a, b)
+
+
+def test_sphere_intersects_kat(oracle):
+    lib = oracle.lib()
+    rows = load("sphere_intersects.json")["rows"]
+    assert len(rows) > 400
+    hits = 0
+    for r in rows:
+        dist = C.c_float(0.0)
+        hit = lib.orc_sphere_intersects(f3(r["c"]), C.c_float(float(fl([r["r"]])[0])), f3(r["o"]), f3(r["d"]), C.byref(dist))
+        assert hit == r["hit"], r
+        if hit:
+            hits += 1
+            assert same_bits([dist.value], fl([r["dist"]])), r
+    assert 50 < hits < len(rows) - 50          # the table exercises both outcomes
+
+
+def test_plane_intersects_kat(oracle):
+    lib = oracle.lib()
+    for r in load("plane_intersects.json")["rows"]:
+        dist = C.c_float(0.0)
+        hit = lib.orc_plane_intersects(f3(r["po"]), f3(r["pn"]), f3(r["o"]), f3(r["d"]), C.byref(dist))
+        assert hit == r["hit"], r
+        if hit:
+            assert same_bits([dist.value], fl([r["dist"]])), r
+
+
+def test_checker_kat(oracle, capi):
+    lib = oracle.lib()
+    g = load("checker.json")
+    seen = set()
+    for r in g["rows"]:
+        w = lib.orc_checker_white(f3(r["pos"]))
+        assert w == r["white"], (r, fl(r["pos"]))
+        seen.add(w)
+    assert seen == {0, 1}
+    # TiledPlane's two materials as rt_make_scene emits them
+    objs, _ = capi.make_scene(capi.RT_SCENE_DEFAULT, 64, 48)
+    plane = objs[len(objs) - 1]
+    assert plane.type == capi.RT_OBJ_TILED_PLANE
+    for name, m in (("white", plane.mat), ("black", plane.mat2)):
+        got = list(m.albedo) + list(m.specular) + [m.reflectance]
+        assert same_bits(got, fl(g["materials"][name]))
+        assert list(m.emissive) == [0.0, 0.0, 0.0]
+
+
+def test_vector_kat(oracle):
+    lib = oracle.lib()
+    for r in load("vectors.json")["rows"]:
+        n, rf, rd = F3(), F3(), F3()
+        lib.orc_sphere_normal(f3(r["c"]), f3(r["p"]), n)
+        lib.orc_ray_from(f3(r["c"]), f3(r["p"]), rf)
+        lib.orc_reflect_dir(f3(r["i"]), n, rd)
+        assert same_bits(list(n), fl(r["normal"]))
+        assert same_bits(list(rf), fl(r["ray_from"]))
+        assert same_bits(list(rd), fl(r["reflect"]))
+
+
+def _cam_list(cam):
+    return (list(cam.position) + list(cam.view_direction) + list(cam.right) + list(cam.up) +
+            [cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height])
+
+
+def test_camera_kat(oracle, capi):
+    lib = oracle.lib()
+    g = load("camera.json")
+    assert g["sizeof"] == {"Material": 40, "Sphere": 64, "TiledPlane": 112, "Camera": 64}
+    assert C.sizeof(capi.Material) == 40 and C.sizeof(capi.Camera) == 64 and C.sizeof(capi.Object) == 112
+    for r in g["rows"]:
+        cam = capi.Camera()
+        lib.orc_camera_init(C.byref(cam), f3(r["pos"]), f3(r["dir"]), C.c_float(float(fl([r["fov"]])[0])), r["w"], r["h"])
+        assert same_bits(_cam_list(cam), fl(r["camera"]))
+        # the product's host helper (rt_camera_init) is the same constructor
+        cam2 = capi.camera_init(fl(r["pos"]), fl(r["dir"]), float(fl([r["fov"]])[0]), r["w"], r["h"])
+        assert same_bits(_cam_list(cam2), fl(r["camera"]))
+        for ray in r["rays"]:
+            s = fl(ray["s"])
+            out = F3()
+            lib.orc_world_ray(C.byref(cam), C.c_float(float(s[0])), C.c_float(float(s[1])), out)
+            assert same_bits(list(out), fl(ray["dir"]))
+
+
+def test_bmp_writer_kat(oracle, capi, tmp_path):
+    for r in load("bmp.json")["rows"]:
+        img = np.random.default_rng(r["seed"]).integers(0, 256, (r["h"], r["w"], 3), dtype=np.uint8)
+        for name, writer in (("oracle", oracle.write_bmp), ("product", capi.write_bmp)):
+            path = str(tmp_path / f"{name}_{r['w']}x{r['h']}.bmp")
+            writer(path, img)
+            data = open(path, "rb").read()
+            assert len(data) == r["bytes"], name
+            assert data[:54].hex() == r["head"], name
+            assert hashlib.md5(data).hexdigest() == r["md5"], name
+
+
+@pytest.fixture(scope="module")
+def default_frames(oracle, capi):
+    """The two renders the reference program can produce: -a 0 and -a 1, 1024x768, depth 5."""
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, 1024, 768)
+    out = {}
+    for a, spp in ((0, 1), (1, 4)):
+        p = capi.render_params(1024, 768, 5, spp)
+        out[a] = oracle.render(objs, cam, p, threads=8, want_stats=True)
+    return objs, cam, out
+
+
+def test_reference_program_md5(oracle, default_frames, tmp_path):
+    """image.bmp of the verbatim program: the end-to-end pin of the trace loop."""
+    pins = load("survey_pins.json")
+    _, _, frames = default_frames
+    for a in (0, 1):
+        path = str(tmp_path / f"a{a}.bmp")
+        oracle.write_bmp(path, frames[a][0])
+        data = open(path, "rb").read()
+        assert len(data) == pins["bmp_header"]["bfSize"]
+        assert hashlib.md5(data).hexdigest() == pins["bmp_md5"][f"a{a}"]
+
+
+def test_reference_program_radiance_and_camera(oracle, capi, default_frames):
+    pins = load("survey_pins.json")
+    _, cam, frames = default_frames
+    f32 = frames[0][1]
+    for key, want in pins["radiance_a0"].items():
+        x, y = map(int, key.split(","))
+        assert same_bits(f32[y, x, :3], [float.fromhex(v) for v in want]), key
+    assert same_bits(list(cam.up), pins["camera"]["up"])
+    assert same_bits(list(cam.view_direction), pins["camera"]["view"])
+    assert same_bits([cam.half_angle, cam.aspect_ratio], [pins["camera"]["half"], pins["camera"]["aspect"]])
+    d = F3()
+    oracle.lib().orc_world_ray(C.byref(cam), C.c_float(512.1), C.c_float(384.2), d)
+    assert same_bits(list(d), [float.fromhex(v) for v in pins["primary_dir_512_384"]])
+
+
+def test_reference_program_counters(default_frames):
+    pins = load("survey_pins.json")
+    _, _, frames = default_frames
+    st = frames[1][2]
+    c = pins["counters_a1"]
+    assert st["calls"] == c["calls"] and st["hits"] == c["hits"] and st["lit"] == c["lit"]
+    assert st["calls_by_depth"][:6] == c["by_depth"]
+    assert st["nearest_tests"] == c["nearest_tests"]
+    assert st["shadow_tests"] == c["shadow_tests_pruned"]
+    assert st["shadow_rays_pruned"] == c["shadow_rays_pruned"]
+    assert st["shadow_rays_verbatim"] == c["shadow_rays_verbatim"]
+    st0 = frames[0][2]
+    assert st0["calls"] == pins["counters_a0"]["calls"] and st0["hits"] == pins["counters_a0"]["hits"]
+
+
+def test_pruned_equals_verbatim(oracle, capi):
+    """looping only over emissive objects is bit-identical to the loop as written."""
+    w, h = 256, 192
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    p = capi.render_params(w, h, 5, 4)
+    rgb_v, f32_v, st_v = oracle.render(objs, cam, p, verbatim=True, threads=8, want_stats=True)
+    rgb_p, f32_p, st_p = oracle.render(objs, cam, p, verbatim=False, threads=8, want_stats=True)
+    assert np.array_equal(rgb_v, rgb_p)
+    assert np.array_equal(f32_v[..., :3].view(np.uint32), f32_p[..., :3].view(np.uint32))
+    assert st_v["shadow_tests"] == 36 * st_v["hits"] and st_p["shadow_tests"] == 12 * st_p["hits"]
+
+
+def test_partition_independence(oracle, capi):
+    """main.cpp:193-196: the image does not depend on the number of threads."""
+    w, h = 160, 120
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    p = capi.render_params(w, h, 5, 1)
+    a = oracle.render(objs, cam, p, threads=1)[0]
+    for t in (2, 3, 8):
+        assert np.array_equal(a, oracle.render(objs, cam, p, threads=t)[0])
+
+
+def test_scene_generators_and_sparse_radiance(oracle, capi):
+    """rt_make_scene is deterministic (sha256 of the object array) and the oracle reproduces the
+    committed full-resolution sparse-pixel radiance of every synthetic scene."""
+    g = load("scenes.json")["scenes"]
+    for name, s in g.items():
+        objs, cam = capi.make_scene(s["kind"], s["w"], s["h"], frame=s["frame"])
+        assert len(objs) == s["n"], name
+        assert hashlib.sha256(bytes(objs)).hexdigest() == s["objects_sha256"], name
+        assert same_bits(_cam_list(cam), fl(s["camera"])), name
+        sxy = fl(s["samples"]).reshape(-1, 2)
+        n = 192 if s["n"] < 2000 else 24          # the 16k scene costs ~0.1 s per path on one core
+        rad = oracle.trace_samples(objs, cam, s["depth"], sxy[:n])
+        assert same_bits(rad.reshape(-1), fl(s["radiance"])[: 3 * n]), name
