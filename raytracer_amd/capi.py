@@ -226,3 +226,43 @@ class Context:
         st = Stats()
         self._check(lib.rt_get_stats(self._h, C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}
+
+
+# ---- scene construction helpers mirroring the reference's constructors -------------------------
+
+def material(albedo=(0, 0, 0), specular=(0, 0, 0), reflectance=0.0, emissive=(0, 0, 0)):
+    """struct Material (sceneobjects.h:3-9)."""
+    m = Material()
+    m.albedo[:] = [float(v) for v in albedo]
+    m.specular[:] = [float(v) for v in specular]
+    m.reflectance = float(reflectance)
+    m.emissive[:] = [float(v) for v in emissive]
+    return m
+
+
+def sphere(mat, center, radius):
+    """Sphere(mat, c, r) (sceneobjects.h:42-47)."""
+    o = Object()
+    o.type = RT_OBJ_SPHERE
+    o.a[:] = [float(v) for v in center]
+    o.radius = float(radius)
+    o.mat = mat
+    return o
+
+
+def tiled_plane(origin, normal, white=None, black=None):
+    """TiledPlane(o, n) (sceneobjects.h:93-104) with its white/black materials (emissive = 0)."""
+    o = Object()
+    o.type = RT_OBJ_TILED_PLANE
+    o.a[:] = [float(v) for v in origin]
+    o.b[:] = [float(v) for v in normal]
+    o.mat = white if white is not None else material((1, 1, 1), (1, 1, 1), 0.6)
+    o.mat2 = black if black is not None else material((0, 0, 0), (0, 0, 0), 0.6)
+    return o
+
+
+def objects(items):
+    arr = (Object * len(items))()
+    for i, it in enumerate(items):
+        arr[i] = it
+    return arr

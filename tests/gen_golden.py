@@ -188,12 +188,15 @@ def main():
                                     ("grid16k", 2, 3840, 2160, 5)):
         objs, cam = capi.make_scene(kind, w, h, frame=17)
         blob = bytes(objs)
-        sxy = np.stack([rng.uniform(0, w, 192), rng.uniform(0, h, 192)], axis=1).astype(np.float32)
+        # pixel-aligned samples at the reference's single-sample offset (.1,.2), main.cpp:202-205
+        px = np.stack([rng.integers(0, w, 192), rng.integers(0, h, 192)], axis=1)
+        sxy = (px.astype(np.float32) + np.array([0.1, 0.2], dtype=np.float32)).astype(np.float32)
         rad = oracle_lib.trace_samples(objs, cam, depth, sxy)
         scenes[name] = {"kind": kind, "w": w, "h": h, "depth": depth, "frame": 17, "n": len(objs),
                         "objects_sha256": hashlib.sha256(blob).hexdigest(),
                         "camera": bits(list(cam.position) + list(cam.view_direction) + list(cam.right) + list(cam.up) +
                                        [cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height]),
+                        "pixels": px.reshape(-1).tolist(),
                         "samples": bits(sxy.reshape(-1)), "radiance": bits(rad.reshape(-1))}
     json.dump({"source": "rt_make_scene + the pinned oracle (orc_trace_samples); full-resolution sparse-pixel pins",
                "scenes": scenes}, open(os.path.join(OUT, "scenes.json"), "w"))
