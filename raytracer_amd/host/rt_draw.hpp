@@ -1,0 +1,65 @@
+// rt_draw.hpp -- DrawScene with the reference's signature (raytracer_cpp/main.cpp:190), served by the
+// MI355X library: the scene list and camera (the reference's globals, main.cpp:18-19) are flattened,
+// uploaded, traced on the device and the frame lands in Bitmap::pData.  There is no CPU path: a
+// failure of any rt_* call is reported through DrawSceneError and nothing is drawn.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+#include "rt_bitmap.hpp"
+#include "rt_camera.hpp"
+#include "rt_scene.hpp"
+
+extern std::vector<std::shared_ptr<SceneObject>> sceneObjects;
+extern std::shared_ptr<Camera> pCamera;
+
+struct DrawSceneError : std::runtime_error {
+    int status;
+    DrawSceneError(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+struct DrawSceneOptions {
+    int maxDepth = 5;           // MAX_DEPTH, main.cpp:16
+    int device = 0;
+    double *kernelMs = nullptr; // optional: device time of the trace kernel
+};
+
+// `partitions` is the reference's CPU thread count; the device schedules its own waves, so the
+// value only has to be positive.  `antialias` selects the reference's 4 fixed sub-pixel samples.
+inline void DrawScene(Bitmap *pBitmap, int partitions, bool antialias, const DrawSceneOptions &opt = DrawSceneOptions())
+{
+    if (!pBitmap || partitions < 1 || !pCamera || sceneObjects.empty())
+        throw DrawSceneError(RT_ERR_INVALID_ARG, "DrawScene: bitmap, camera and a non-empty scene are required");
+    std::vector<rt_object> flat(sceneObjects.size());
+    for (size_t i = 0; i < sceneObjects.size(); i++) sceneObjects[i]->Flatten(flat[i]);   // list order is semantic
+    const rt_camera cam = pCamera->Flatten();
+
+    rt_context *ctx = nullptr;
+    int rc = rt_create(&ctx, opt.device);
+    if (rc != RT_OK) throw DrawSceneError(rc, rt_last_error(nullptr));
+    auto fail = [&](int code) {
+        const std::string msg = rt_last_error(ctx);
+        rt_destroy(ctx);
+        throw DrawSceneError(code, msg);
+    };
+    if ((rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size(), &cam)) != RT_OK) fail(rc);
+    rt_render_params p{};
+    p.width = pBitmap->width;
+    p.height = pBitmap->height;
+    p.max_depth = opt.maxDepth;
+    p.spp = antialias ? 4 : 1;                 // main.cpp:200
+    p.outputs = RT_OUT_RGBA8;
+    p.mode = RT_MODE_EXACT;
+    if ((rc = rt_render(ctx, &p)) != RT_OK) fail(rc);
+    if (opt.kernelMs) {
+        rt_stats st{};
+        if ((rc = rt_get_stats(ctx, &st)) != RT_OK) fail(rc);
+        *opt.kernelMs = st.kernel_ms;
+    }
+    const size_t bytes = (size_t)pBitmap->width * (size_t)pBitmap->height * sizeof(Color);
+    if ((rc = rt_download_framebuffer(ctx, pBitmap->pData, bytes, RT_FMT_RGB8)) != RT_OK) fail(rc);
+    rt_destroy(ctx);
+}

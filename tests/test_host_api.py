@@ -1,0 +1,99 @@
+"""The host C++ API (raytracer_amd/host): the reference's class surface on top of the C ABI.
+
+CPU: its classes reproduce the golden fixtures bit for bit; the host program fails loudly without
+a device.  GPU: the host program writes the reference program's image.bmp (md5 pins)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MAIN = os.path.join(ROOT, "raytracer_amd", "host", "rt_main")
+F3 = C.c_float * 3
+
+
+def fl(bits):
+    return np.asarray(bits, dtype=np.uint32).view(np.float32)
+
+
+def f3(bits):
+    return F3(*[float(x) for x in fl(bits)])
+
+
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a, dtype=np.float32).view(np.uint32), np.asarray(b, dtype=np.float32).view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def shim(capi):
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libhostshim.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "raytracer_amd", "host"),
+                           "-o", so, os.path.join(ROOT, "tests", "host_shim.cpp"),
+                           "-L" + os.path.join(ROOT, "raytracer_amd"), "-lrt_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "raytracer_amd")])
+    return C.CDLL(so)
+
+
+def test_host_classes_match_reference_fixtures(shim, capi):
+    for r in json.load(open(os.path.join(GOLD, "sphere_intersects.json")))["rows"]:
+        dist = C.c_float(0.0)
+        hit = shim.host_sphere_intersects(f3(r["c"]), C.c_float(float(fl([r["r"]])[0])), f3(r["o"]), f3(r["d"]), C.byref(dist))
+        assert hit == r["hit"] and (not hit or same_bits([dist.value], fl([r["dist"]])))
+    for r in json.load(open(os.path.join(GOLD, "plane_intersects.json")))["rows"]:
+        dist = C.c_float(0.0)
+        hit = shim.host_plane_intersects(f3(r["po"]), f3(r["pn"]), f3(r["o"]), f3(r["d"]), C.byref(dist))
+        assert hit == r["hit"] and (not hit or same_bits([dist.value], fl([r["dist"]])))
+    for r in json.load(open(os.path.join(GOLD, "checker.json")))["rows"]:
+        assert shim.host_checker_white(f3(r["pos"])) == r["white"]
+    for r in json.load(open(os.path.join(GOLD, "vectors.json")))["rows"]:
+        n, rf, rd = F3(), F3(), F3()
+        shim.host_vectors(f3(r["c"]), f3(r["p"]), f3(r["i"]), n, rf, rd)
+        assert same_bits(list(n), fl(r["normal"])) and same_bits(list(rf), fl(r["ray_from"])) and same_bits(list(rd), fl(r["reflect"]))
+    for r in json.load(open(os.path.join(GOLD, "camera.json")))["rows"]:
+        for ray in r["rays"]:
+            cam, out, s = capi.Camera(), F3(), fl(ray["s"])
+            shim.host_camera(f3(r["pos"]), f3(r["dir"]), C.c_float(float(fl([r["fov"]])[0])), r["w"], r["h"], C.byref(cam),
+                             C.c_float(float(s[0])), C.c_float(float(s[1])), out)
+            got = (list(cam.position) + list(cam.view_direction) + list(cam.right) + list(cam.up) +
+                   [cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height])
+            assert same_bits(got, fl(r["camera"])) and same_bits(list(out), fl(ray["dir"]))
+
+
+def test_host_flatten(shim, capi):
+    s, p = capi.Object(), capi.Object()
+    shim.host_flatten(C.byref(s), C.byref(p))
+    assert s.type == capi.RT_OBJ_SPHERE and list(s.a) == [1.0, 2.0, 3.0] and s.radius == 4.0
+    assert same_bits(list(s.mat.albedo) + list(s.mat.specular) + [s.mat.reflectance] + list(s.mat.emissive),
+                     [.1, .2, .3, .4, .5, .6, .7, .8, .9, 1.0])
+    ref_plane = capi.make_scene(capi.RT_SCENE_DEFAULT, 8, 8)[0][5]
+    assert bytes(p) == bytes(ref_plane)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_host_program_fails_loudly_without_gpu(tmp_path):
+    r = subprocess.run([MAIN, "-a", "0"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU path" in r.stderr
+    assert not (tmp_path / "image.bmp").exists()
+    r = subprocess.run([MAIN, "--bogus"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "partitions" in r.stderr and "antialiased" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,key", [(["-a", "0"], "a0"), ([], "a1"), (["-p", "8", "--antialiased=1"], "a1")])
+def test_host_program_writes_reference_image(tmp_path, args, key):
+    """raytracer_cpp's CLI contract: defaults -p 2 -a 1, image.bmp in the working directory, whose
+    md5 is the one the verbatim program produced."""
+    pins = json.load(open(os.path.join(GOLD, "survey_pins.json")))
+    r = subprocess.run([MAIN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("Time: ")
+    data = open(tmp_path / "image.bmp", "rb").read()
+    assert hashlib.md5(data).hexdigest() == pins["bmp_md5"][key]
