@@ -154,6 +154,7 @@ def main():
             "config": {"workload": f"{args.scene}: {len(objs)} objects ({n_sph} spheres, {st['n_emitters']} emissive), "
                                    f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}",
                        "rays_per_frame": int(rays), "bands": bounds,
+                       "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit")},
                        "parallelism": f"row-bands x{world}" + (" + RCCL gather" if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,

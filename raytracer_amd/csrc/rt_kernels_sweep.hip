@@ -22,6 +22,12 @@
 // The result is bit-identical to the reference while the hot loop runs ~6 VALU lane-ops per test
 // instead of the ~17 of the straight transcription (rt_kernels_exact.hip, kept for A/B).
 //
+// Ray compaction: lanes of a tile die at different depths, so after the primary sweep the live
+// hit points of the whole workgroup (4 tiles) are packed into a dense request queue in LDS each
+// level; thread t then sweeps request t, so the waves that do sweep are full, and the result goes
+// back through the same LDS slots to the pixel's home lane.  Requests that need a reflection ray
+// are packed first, so trailing waves sweep K = E rays instead of E + 1.
+//
 // The recursion of TraceRay (main.cpp:84-188) is unrolled without a stack: the hit chain is traced
 // forward (one combined sweep per segment also settles that segment's shadow rays as a bit mask),
 // then shading runs deepest-first in the reference's operation order.
@@ -111,6 +117,25 @@ __device__ __forceinline__ void stage(const RtSceneDev &sc, float4 *lds, int cap
     }
     __syncthreads();
 }
+
+// Camera-relative table only (LDS-resident scenes): rebuilt per sample because the request queue
+// of the bounce levels reuses its LDS region.
+__device__ __forceinline__ void build_cam_table(float4 *lds, int cap, int count, V3 cam)
+{
+    __syncthreads();
+    for (int p = threadIdx.x; p < count; p += kBlock) {
+        const float4 A = lds[2 * p], B = lds[2 * p + 1];
+        f2 ux = f2{A.x, A.y} - splat(cam.x), uy = f2{A.z, A.w} - splat(cam.y), uz = f2{B.x, B.y} - splat(cam.z);
+        f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
+        f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
+        lds[2 * cap + 2 * p] = make_float4(ux.x, ux.y, uy.x, uy.y);
+        lds[2 * cap + 2 * p + 1] = make_float4(uz.x, uz.y, w.x, w.y);
+    }
+    __syncthreads();
+}
+
+constexpr int kQueueFields = 7;                          // request: pos, refl, -; result: lit, alt, dist, slot, id
+constexpr int kQueueFloat4 = kQueueFields * kBlock / 4;  // LDS the queue needs, in float4
 
 template <int K>
 __device__ __forceinline__ void exact_pair(RaySet<K> &r, const f2 (&q)[K], float bound, float4 A, float4 B, int slot0,
@@ -302,7 +327,9 @@ __device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc,
     }
 }
 
-template <bool CHUNKED, bool STATS>
+// COMPACT: pack the live hit points of the workgroup before every bounce sweep (pays off once a
+// sweep is long enough to dwarf three barriers: scenes of more than a few dozen spheres).
+template <bool CHUNKED, bool COMPACT, bool STATS>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
@@ -326,7 +353,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
     const V3 cam_right = v3(cam.right[0], cam.right[1], cam.right[2]);
     const V3 cam_up = v3(cam.up[0], cam.up[1], cam.up[2]);
 
-    if (!CHUNKED) stage<false>(sc, lds, cap, 0, (sc.n_spheres + 1) >> 1, true, cam_pos);
+    __shared__ int q_count[2];                        // [0] requests with a reflection ray, [1] without
+    unsigned *const queue = reinterpret_cast<unsigned *>(lds + 2 * cap);   // aliases the camera table
+    if (threadIdx.x == 0) q_count[0] = q_count[1] = 0;
+    if (!CHUNKED) stage<false>(sc, lds, cap, 0, (sc.n_spheres + 1) >> 1, false, cam_pos);
 
     // one record per path segment, read back deepest-first (runtime-indexed -> private memory)
     float rec_pos[RT_MAX_LEVELS][3], rec_n[RT_MAX_LEVELS][3], rec_r[RT_MAX_LEVELS][3];
@@ -352,6 +382,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
             r.d[0] = normalize(d);
             r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
             r.act[0] = in_image;
+            if (!CHUNKED) build_cam_table(lds, cap, (sc.n_spheres + 1) >> 1, cam_pos);
             sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
             merge_planes<1>(sc, in_image, r);
             seg.o = r.o[0]; seg.d = r.d[0]; seg.dist = r.best[0]; seg.slot = r.slot[0]; seg.id = r.id[0];
@@ -360,57 +391,135 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
         bool miss_tail = in_image && !alive;                                 // main.cpp:90-93
         int nlev = 0;
 
-        // ---- forward: hit chain + shadow masks ----
+        // ---- forward: hit chain + shadow masks, live hit points compacted across the workgroup ----
         for (int depth = 0; depth <= fr.max_depth; depth++) {
-            if (!block_any<CHUNKED>(alive)) break;
-            V3 pos = cam_pos, n = v3(0, 0, 0), refl = n;
+            V3 pos = cam_pos, refl = v3(0, 0, 0);
             bool want_refl = false;
-            if (alive) {
-                if (STATS) n_hits++;
-                pos = seg.o + seg.d * seg.dist;                              // main.cpp:94
-                int mat;
-                if (seg.slot >= 0) {
-                    const float4 A = sc.pairs[2 * (seg.slot >> 1)], B = sc.pairs[2 * (seg.slot >> 1) + 1];
-                    const V3 c = (seg.slot & 1) ? v3(A.y, A.w, B.y) : v3(A.x, A.z, B.x);
-                    n = normalize(pos - c);                                  // sceneobjects.h:59-62
-                    mat = 2 * seg.id;
-                } else {
-                    const RtPlaneDev p = sc.planes[-1 - seg.slot];
-                    n = v3(p.nx, p.ny, p.nz);                                // sceneobjects.h:117-120
-                    mat = 2 * seg.id + (checker_white(pos) ? 0 : 1);         // sceneobjects.h:106-115
+            int my_slot = 0;
+            if (COMPACT) __syncthreads();     // previous level's results are consumed, counters are reset
+            else if (!block_any<CHUNKED>(alive)) break;
+            {
+                if (alive) {
+                    if (STATS) n_hits++;
+                    pos = seg.o + seg.d * seg.dist;                          // main.cpp:94
+                    V3 n;
+                    int mat;
+                    if (seg.slot >= 0) {
+                        const float4 A = sc.pairs[2 * (seg.slot >> 1)], B = sc.pairs[2 * (seg.slot >> 1) + 1];
+                        const V3 c = (seg.slot & 1) ? v3(A.y, A.w, B.y) : v3(A.x, A.z, B.x);
+                        n = normalize(pos - c);                              // sceneobjects.h:59-62
+                        mat = 2 * seg.id;
+                    } else {
+                        const RtPlaneDev p = sc.planes[-1 - seg.slot];
+                        n = v3(p.nx, p.ny, p.nz);                            // sceneobjects.h:117-120
+                        mat = 2 * seg.id + (checker_white(pos) ? 0 : 1);     // sceneobjects.h:106-115
+                    }
+                    refl = normalize(reflect(seg.d, n));                     // main.cpp:100
+                    rec_pos[nlev][0] = pos.x; rec_pos[nlev][1] = pos.y; rec_pos[nlev][2] = pos.z;
+                    rec_n[nlev][0] = n.x; rec_n[nlev][1] = n.y; rec_n[nlev][2] = n.z;
+                    rec_r[nlev][0] = refl.x; rec_r[nlev][1] = refl.y; rec_r[nlev][2] = refl.z;
+                    rec_mat[nlev] = mat;
+                    want_refl = depth < fr.max_depth && sc.mats[mat].reflectance > 0.0f;   // main.cpp:103
+                    if (want_refl) n_refl++;
+                    n_shadow += sc.n_emit;
                 }
-                refl = normalize(reflect(seg.d, n));                         // main.cpp:100
-                rec_pos[nlev][0] = pos.x; rec_pos[nlev][1] = pos.y; rec_pos[nlev][2] = pos.z;
-                rec_n[nlev][0] = n.x; rec_n[nlev][1] = n.y; rec_n[nlev][2] = n.z;
-                rec_r[nlev][0] = refl.x; rec_r[nlev][1] = refl.y; rec_r[nlev][2] = refl.z;
-                rec_mat[nlev] = mat;
-                want_refl = depth < fr.max_depth && sc.mats[mat].reflectance > 0.0f;   // main.cpp:103
-                if (want_refl) n_refl++;
-                n_shadow += sc.n_emit;
+                // enqueue: one LDS atomic per wave and class, lanes take consecutive slots
+                if constexpr (COMPACT) {
+                const unsigned long long m_refl = __ballot(alive && want_refl), m_plain = __ballot(alive && !want_refl);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                int base_refl = 0, base_plain = 0;
+                if (lane == 0) {
+                    if (m_refl) base_refl = atomicAdd(&q_count[0], __popcll(m_refl));
+                    if (m_plain) base_plain = atomicAdd(&q_count[1], __popcll(m_plain));
+                }
+                base_refl = __shfl(base_refl, 0, 64);
+                base_plain = __shfl(base_plain, 0, 64);
+                if (alive) {
+                    my_slot = want_refl ? base_refl + __popcll(m_refl & below)
+                                        : kBlock - 1 - (base_plain + __popcll(m_plain & below));
+                    queue[0 * kBlock + my_slot] = __float_as_uint(pos.x);
+                    queue[1 * kBlock + my_slot] = __float_as_uint(pos.y);
+                    queue[2 * kBlock + my_slot] = __float_as_uint(pos.z);
+                    queue[3 * kBlock + my_slot] = __float_as_uint(refl.x);
+                    queue[4 * kBlock + my_slot] = __float_as_uint(refl.y);
+                    queue[5 * kBlock + my_slot] = __float_as_uint(refl.z);
+                }
+                }
             }
+            int n_front = 0, n_total = 0;
+            if constexpr (COMPACT) {
+                __syncthreads();
+                n_front = q_count[0];
+                n_total = n_front + q_count[1];
+                if (n_total == 0) break;                                      // uniform: no live path in the workgroup
+            }
+
+            // ---- worker phase: thread t sweeps request t (its own hit point when not compacting) ----
             unsigned long long lit = 0, alt = 0;
-            Segment next = seg;
+            Segment next;
+            next.dist = 0.0f; next.slot = INT_MIN; next.id = -1;
             bool next_hit = false;
-            const bool any_refl = block_any<CHUNKED>(want_refl);
-            int e0 = 0;
-            if (any_refl) {
-                const int ne = min(sc.n_emit, kMaxK - 1);
-                trace_group_k<true, CHUNKED>(1 + ne, sc, lds, cap, alive, pos, refl, want_refl, 0, lit, alt, next, next_hit);
-                e0 = ne;
+            {
+                const int t = threadIdx.x;
+                const bool w_on = COMPACT ? t < n_total : alive;
+                const bool w_refl = COMPACT ? t < n_front : want_refl;
+                const int w_slot = w_refl ? t : kBlock - 1 - (t - n_front);
+                V3 w_pos = pos, w_dir = refl;
+                if (COMPACT && w_on) {
+                    w_pos = v3(__uint_as_float(queue[0 * kBlock + w_slot]), __uint_as_float(queue[1 * kBlock + w_slot]),
+                               __uint_as_float(queue[2 * kBlock + w_slot]));
+                    w_dir = v3(__uint_as_float(queue[3 * kBlock + w_slot]), __uint_as_float(queue[4 * kBlock + w_slot]),
+                               __uint_as_float(queue[5 * kBlock + w_slot]));
+                }
+                // chunked sweeps contain workgroup barriers, so every wave must take the same path there
+                const bool any_refl = COMPACT ? (CHUNKED ? n_front > 0 : wave * 64 < n_front) : block_any<CHUNKED>(want_refl);
+                int e0 = 0;
+                if (any_refl) {
+                    const int ne = min(sc.n_emit, kMaxK - 1);
+                    trace_group_k<true, CHUNKED>(1 + ne, sc, lds, cap, w_on, w_pos, w_dir, w_refl, 0, lit, alt, next, next_hit);
+                    e0 = ne;
+                }
+                while (e0 < sc.n_emit) {
+                    const int ne = min(sc.n_emit - e0, kMaxK);
+                    trace_group_k<false, CHUNKED>(ne, sc, lds, cap, w_on, w_pos, w_dir, false, e0, lit, alt, next, next_hit);
+                    e0 += ne;
+                }
+                if (COMPACT && w_on) {
+                    queue[0 * kBlock + w_slot] = (unsigned)lit;
+                    queue[1 * kBlock + w_slot] = (unsigned)(lit >> 32);
+                    queue[2 * kBlock + w_slot] = (unsigned)alt;
+                    queue[3 * kBlock + w_slot] = (unsigned)(alt >> 32);
+                    queue[4 * kBlock + w_slot] = __float_as_uint(next.dist);
+                    queue[5 * kBlock + w_slot] = (unsigned)(next_hit ? next.slot : INT_MIN);
+                    queue[6 * kBlock + w_slot] = (unsigned)next.id;
+                }
             }
-            while (e0 < sc.n_emit) {
-                const int ne = min(sc.n_emit - e0, kMaxK);
-                trace_group_k<false, CHUNKED>(ne, sc, lds, cap, alive, pos, refl, false, e0, lit, alt, next, next_hit);
-                e0 += ne;
+            if constexpr (COMPACT) {
+                __syncthreads();
+                if (threadIdx.x == 0) q_count[0] = q_count[1] = 0;
+                if (alive) {         // home phase: take the result back
+                    lit = (unsigned long long)queue[0 * kBlock + my_slot] | ((unsigned long long)queue[1 * kBlock + my_slot] << 32);
+                    alt = (unsigned long long)queue[2 * kBlock + my_slot] | ((unsigned long long)queue[3 * kBlock + my_slot] << 32);
+                    next.dist = __uint_as_float(queue[4 * kBlock + my_slot]);
+                    next.slot = (int)queue[5 * kBlock + my_slot];
+                    next.id = (int)queue[6 * kBlock + my_slot];
+                }
+            } else if (!next_hit) {
+                next.slot = INT_MIN;
             }
             if (alive) {
                 rec_lit[nlev] = lit;
                 rec_alt[nlev] = alt;
                 nlev++;
                 if (want_refl) {
-                    seg = next;
-                    alive = next_hit;
-                    miss_tail = !next_hit;
+                    const int hit_slot = next.slot;
+                    seg.o = pos + refl * 0.001f;                             // main.cpp:108
+                    seg.d = refl;
+                    seg.dist = next.dist;
+                    seg.slot = hit_slot;
+                    seg.id = next.id;
+                    alive = hit_slot != INT_MIN;
+                    miss_tail = !alive;
                 } else {
                     alive = false;
                 }
@@ -489,13 +598,18 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const dim3 grid((tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
     const int n_pairs = (scene.n_spheres + 1) / 2;
     const bool chunked = frame.chunk < n_pairs;
-    const size_t lds_bytes = (size_t)(frame.chunk > 0 ? frame.chunk : 1) * 4 * sizeof(float4);
+    const int cap = frame.chunk > 0 ? frame.chunk : 1;
+    const size_t lds_bytes = (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
+    // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
+    const bool compact = n_pairs >= 24;
+#define RT_LAUNCH(C, P, S) hipLaunchKernelGGL((trace_sweep_kernel<C, P, S>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats)
     if (chunked) {
-        if (stats) hipLaunchKernelGGL((trace_sweep_kernel<true, true>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
-        else hipLaunchKernelGGL((trace_sweep_kernel<true, false>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+        if (stats) RT_LAUNCH(true, true, true); else RT_LAUNCH(true, true, false);
+    } else if (compact) {
+        if (stats) RT_LAUNCH(false, true, true); else RT_LAUNCH(false, true, false);
     } else {
-        if (stats) hipLaunchKernelGGL((trace_sweep_kernel<false, true>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
-        else hipLaunchKernelGGL((trace_sweep_kernel<false, false>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats);
+        if (stats) RT_LAUNCH(false, false, true); else RT_LAUNCH(false, false, false);
     }
+#undef RT_LAUNCH
     return hipGetLastError();
 }
