@@ -2,9 +2,14 @@
 """bench.py -- Mrays/s of the trace loop on MI355X, with roofline and a CPU baseline.
 
 A step = one frame of the workload: the synthetic "grid-1024" scene (1024 jittered spheres + 4
-emissive spheres + tiled plane, SURVEY.md 8d config 4's scene) at 3840x2160, MAX_DEPTH 5, 1 sample
-per pixel (the metric's "4K depth 5").  With N ranks the frame is cut into N cost-balanced row
-bands (one per GPU) and the RGBA8 bands are gathered to rank 0 over RCCL: strong scaling.
+emissive spheres + tiled plane, SURVEY.md 8d config 4's scene) at 3840x2160, MAX_DEPTH 5 (the
+metric's "4K depth 5"), antialiased with the reference's 4 fixed samples per pixel (its CLI default,
+-a 1, raytracer_cpp/main.cpp:234).  With N ranks the frame is cut into N cost-balanced row bands
+(one per GPU) and the RGBA8 bands are gathered to rank 0 over RCCL: strong scaling.
+
+Renders are enqueued on a torch stream (rt_set_stream) so that kernel, gather and assembly order
+on the device without host round trips; the trace kernel's duration is measured per launch with HIP
+events on that stream over the timed region (rt_stats.kernel_ms_total).
 
 Rays = primary + reflection + shadow (one per hit x emissive object), counted once by a
 stats-enabled render outside the timed region.  Inputs (scene, camera) are resident in HBM before
@@ -51,7 +56,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--depth", type=int, default=5)
-    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -102,12 +107,14 @@ def main():
     my_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
 
     params = capi.render_params(W, H, args.depth, args.spp, rows=(y0, y1), mode=mode)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
 
     def step():
-        ctx.render(params)                                  # returns when the band is complete
-        if world > 1:
-            multigpu.gather_bands(band, bounds, rank, world, out=frame)
-        return ctx.stats()["kernel_ms"]
+        with torch.cuda.stream(stream):
+            ctx.render(params, wait=False)                  # enqueue only
+            if world > 1:
+                multigpu.gather_bands(band, bounds, rank, world, out=frame)
 
     def fence():
         if world > 1:
@@ -117,12 +124,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    before = ctx.stats()
+    fence()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
     for _ in range(args.steps):
-        kernel_ms += step()
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    after = ctx.stats()
+    assert after["kernels_timed"] - before["kernels_timed"] == args.steps
+    kernel_ms = after["kernel_ms_total"] - before["kernel_ms_total"]
 
     tot = torch.tensor([elapsed, float(my_rays), float(my_flop), kernel_ms / max(1, args.steps)],
                        dtype=torch.float64, device=dev)
@@ -168,6 +179,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind)
         print(json.dumps(out), flush=True)
 
+    ctx.set_stream(0)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

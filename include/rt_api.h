@@ -129,7 +129,9 @@ typedef struct rt_stats {
     uint64_t plane_tests;
     uint64_t n_objects;
     uint64_t n_emitters;
-    double kernel_ms;           /* device time of the last rt_render (HIP events)                 */
+    double kernel_ms;           /* device time of the last rt_render's trace kernel (HIP events)  */
+    double kernel_ms_total;     /* cumulative over every render of this context ...               */
+    uint64_t kernels_timed;     /* ... and how many launches that covers                          */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -162,6 +164,10 @@ int rt_bind_framebuffer(rt_context *ctx, int32_t plane, void *device_ptr, size_t
 
 /* Stream the caller's work should be ordered against (hipStream_t as void*). */
 int rt_get_stream(rt_context *ctx, void **out_stream);
+/* Makes the context enqueue on the caller's stream (hipStream_t as void*; NULL = back to the
+ * context's own stream), so renders order with the caller's other device work (gathers, copies)
+ * without host synchronisation.  The caller keeps the stream alive while it is set. */
+int rt_set_stream(rt_context *ctx, void *stream);
 /* Enqueue-only render: like rt_render but returns without waiting; rt_sync waits.  The trace
  * kernel's HIP events are still recorded and read by rt_get_stats after rt_sync. */
 int rt_render_async(rt_context *ctx, const rt_render_params *params);

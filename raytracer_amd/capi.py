@@ -52,12 +52,13 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
-                 "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + [("kernel_ms", C.c_double)]
+                 "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + \
+               [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("kernels_timed", C.c_uint64)]
 
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_render", "rt_download_framebuffer",
-    "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_render_async",
+    "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
     "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
     "rt_make_scene", "rt_split_bands", "rt_write_bmp",
 ]
@@ -81,6 +82,7 @@ def _load():
     lib.rt_framebuffer_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rt_bind_framebuffer.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.rt_set_stream.argtypes = [vp, vp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = C.c_char_p
@@ -200,6 +202,10 @@ class Context:
         s = C.c_void_p()
         self._check(lib.rt_get_stream(self._h, C.byref(s)))
         return s.value or 0
+
+    def set_stream(self, stream_handle):
+        """hipStream_t as an int (e.g. torch.cuda.Stream().cuda_stream); 0/None = the context's own."""
+        self._check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle or None)))
 
     def bind_framebuffer(self, plane, ptr, nbytes):
         self._check(lib.rt_bind_framebuffer(self._h, plane, C.c_void_p(ptr), nbytes))

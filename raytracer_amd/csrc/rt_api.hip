@@ -7,14 +7,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
+#include <utility>
 #include <vector>
 
 struct rt_context {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;     // own_stream or the caller's (rt_set_stream)
+    std::vector<hipEvent_t> ev_free;  // recycled event pairs (2 entries per launch)
+    std::deque<std::pair<hipEvent_t, hipEvent_t>> ev_pending;   // launches not yet read back
+    double kernel_ms_last = 0.0, kernel_ms_total = 0.0;
+    uint64_t kernels_timed = 0;
     char err[512] = {0};
 
     // scene
@@ -68,6 +73,36 @@ static bool emissive_nonzero(const rt_material &m)
     return !(m.emissive[0] == 0.0f && m.emissive[1] == 0.0f && m.emissive[2] == 0.0f);  // main.cpp:131
 }
 
+// Reads back every finished launch's event pair into the running totals.  `block`: wait for all.
+static int drain_events(rt_context *ctx, bool block)
+{
+    while (!ctx->ev_pending.empty()) {
+        auto p = ctx->ev_pending.front();
+        if (block) RT_HIP(ctx, hipEventSynchronize(p.second));
+        else if (hipEventQuery(p.second) != hipSuccess) break;
+        float ms = 0.0f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, p.first, p.second));
+        ctx->kernel_ms_last = (double)ms;
+        ctx->kernel_ms_total += (double)ms;
+        ctx->kernels_timed++;
+        ctx->ev_free.push_back(p.first);
+        ctx->ev_free.push_back(p.second);
+        ctx->ev_pending.pop_front();
+    }
+    return RT_OK;
+}
+
+static int take_event(rt_context *ctx, hipEvent_t *out)
+{
+    if (!ctx->ev_free.empty()) {
+        *out = ctx->ev_free.back();
+        ctx->ev_free.pop_back();
+        return RT_OK;
+    }
+    RT_HIP(ctx, hipEventCreate(out));
+    return RT_OK;
+}
+
 extern "C" {
 
 int rt_create(rt_context **out, int device_id)
@@ -86,9 +121,8 @@ int rt_create(rt_context **out, int device_id)
     const char *kern = getenv("RT_AMD_KERNEL");
     ctx->simple_kernel = kern && strcmp(kern, "simple") == 0;
     e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->stats_dev, sizeof(RtStatsDev));
     if (e != hipSuccess) {
         fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e));
@@ -108,9 +142,9 @@ void rt_destroy(rt_context *ctx)
     for (int i = 0; i < 2; i++)
         if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
     if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -294,19 +328,29 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         sdev = ctx->stats_dev;
         RT_HIP(ctx, hipMemsetAsync(sdev, 0, sizeof(RtStatsDev), ctx->stream));
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->ev_pending.size() >= 256) {          // bound the pool: fold the oldest launches in
+        int rc = drain_events(ctx, false);
+        if (rc) return rc;
+        if (ctx->ev_pending.size() >= 256) {
+            RT_HIP(ctx, hipEventSynchronize(ctx->ev_pending.front().second));
+            if ((rc = drain_events(ctx, false))) return rc;
+        }
+    }
+    hipEvent_t ev0, ev1;
+    { int rc = take_event(ctx, &ev0); if (rc) return rc; rc = take_event(ctx, &ev1); if (rc) return rc; }
+    RT_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     if (px > 0) {
         // One kernel serves both modes: it is bit-exact (RT_MODE_EXACT), which is a superset of
         // RT_MODE_FAST's 1e-4 contract.
         if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
         else RT_HIP(ctx, rt_launch_trace_sweep(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
+    ctx->ev_pending.emplace_back(ev0, ev1);
 
     ctx->frame = fr;
     ctx->have_frame = true;
     ctx->last_outputs = outputs;
-    ctx->timed = true;
     ctx->stats_pending = p->collect_stats != 0;
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.primary_rays = (uint64_t)px * (uint64_t)p->spp;
@@ -334,6 +378,16 @@ int rt_get_stream(rt_context *ctx, void **out_stream)
 {
     if (!ctx || !out_stream) return RT_ERR_INVALID_ARG;
     *out_stream = (void *)ctx->stream;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_context *ctx, void *stream)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));      // nothing of ours is left on the old stream
+    { int rc = drain_events(ctx, true); if (rc) return rc; }
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     return RT_OK;
 }
 
@@ -419,11 +473,10 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
     if (!ctx->have_frame) return fail(ctx, RT_ERR_NO_FRAME, "rt_get_stats: nothing rendered yet");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->timed) {
-        float ms = 0.0f;
-        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        ctx->stats.kernel_ms = (double)ms;
-    }
+    { int rc = drain_events(ctx, true); if (rc) return rc; }
+    ctx->stats.kernel_ms = ctx->kernel_ms_last;
+    ctx->stats.kernel_ms_total = ctx->kernel_ms_total;
+    ctx->stats.kernels_timed = ctx->kernels_timed;
     if (ctx->stats_pending) {
         RtStatsDev h;
         RT_HIP(ctx, hipMemcpy(&h, ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost));
