@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -73,11 +75,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace loop has no CPU fallback")
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
     mode = capi.RT_MODE_EXACT if args.mode == "exact" else capi.RT_MODE_FAST
@@ -113,8 +121,15 @@ def main():
     def step():
         with torch.cuda.stream(stream):
             ctx.render(params, wait=False)                  # enqueue only
-            if world > 1:
+            if world == 1:
+                frame.copy_(band, non_blocking=True)        # the N = 1 "assembly"
+            if world > 1 and not rehearsal:
                 multigpu.gather_bands(band, bounds, rank, world, out=frame)
+        if world > 1 and rehearsal:
+            stream.synchronize()
+            host = multigpu.gather_bands(band.cpu(), bounds, rank, world)
+            if rank == 0:
+                frame.copy_(host)
 
     def fence():
         if world > 1:
@@ -136,7 +151,7 @@ def main():
     kernel_ms = after["kernel_ms_total"] - before["kernel_ms_total"]
 
     tot = torch.tensor([elapsed, float(my_rays), float(my_flop), kernel_ms / max(1, args.steps)],
-                       dtype=torch.float64, device=dev)
+                       dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -166,7 +181,7 @@ def main():
                                    f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}",
                        "rays_per_frame": int(rays), "bands": bounds,
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit")},
-                       "parallelism": f"row-bands x{world}" + (" + RCCL gather" if world > 1 else "")},
+                       "parallelism": f"row-bands x{world}" + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": None,
@@ -175,6 +190,7 @@ def main():
                          "note": "15 FLOP x rays x spheres + 5 FLOP x rays x planes (SURVEY 8d lower bound); "
                                  "HBM traffic is the framebuffer only (4 B/px)"},
         }
+        out["config"]["frame_crc"] = int(frame.to(torch.int64).sum().item() & 0xFFFFFFFF)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind)
         print(json.dumps(out), flush=True)
