@@ -42,7 +42,7 @@ struct rt_context {
     RtStatsDev *stats_dev = nullptr;
     rt_stats stats = {};
     bool stats_pending = false;
-    int lds_budget = 40 * 1024;       // per workgroup: 4 workgroups of 4 waves fit a CU's 160 KiB
+    int lds_budget = 39 * 1024;       // per workgroup: 4 workgroups (+ their few static bytes) fit a CU's 160 KiB
     bool simple_kernel = false;       // RT_AMD_KERNEL=simple: the straight-transcription kernel (A/B)
 };
 
@@ -120,6 +120,10 @@ int rt_create(rt_context **out, int device_id)
     ctx->device = device_id;
     const char *kern = getenv("RT_AMD_KERNEL");
     ctx->simple_kernel = kern && strcmp(kern, "simple") == 0;
+    if (const char *kb = getenv("RT_AMD_LDS_KB")) {       // tuning knob: LDS bytes a workgroup may stage
+        int v = atoi(kb);
+        if (v >= 8 && v <= 160) ctx->lds_budget = v * 1024;
+    }
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;

@@ -177,6 +177,8 @@ __device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap
         const int count = min(cap, n_pairs - base);
         if (CHUNKED) stage<true>(sc, lds, cap, base, count, false, pos);
         if (lane_on) {
+            // (Measured: prefetching the next pair by hand costs 15 %; four waves per SIMD already
+            // cover the LDS latency.)
 #pragma unroll 2
             for (int p = 0; p < count; p++) {
                 const float4 A = lds[2 * p], B = lds[2 * p + 1];
@@ -184,13 +186,18 @@ __device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap
                 const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
                 const f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
                 f2 q[K];
-                float m = FLT_MAX;
+                // the K chains are independent: issue them stage by stage
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const f2 s = pk_fma(uz, dz[k], pk_fma(uy, dy[k], ux * dx[k]));
-                    q[k] = pk_fma(-s, s, w);
-                    m = fminf(fminf(m, q[k].x), q[k].y);
-                }
+                for (int k = 0; k < K; k++) q[k] = ux * dx[k];
+#pragma unroll
+                for (int k = 0; k < K; k++) q[k] = pk_fma(uy, dy[k], q[k]);
+#pragma unroll
+                for (int k = 0; k < K; k++) q[k] = pk_fma(uz, dz[k], q[k]);
+#pragma unroll
+                for (int k = 0; k < K; k++) q[k] = pk_fma(-q[k], q[k], w);
+                float m = fminf(q[0].x, q[0].y);
+#pragma unroll
+                for (int k = 1; k < K; k++) m = fminf(fminf(m, q[k].x), q[k].y);
                 if (m <= bound) exact_pair<K>(r, q, bound, A, B, 2 * (base + p), sc.n_spheres);
             }
         }
@@ -602,7 +609,15 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const size_t lds_bytes = (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     const bool compact = n_pairs >= 24;
-#define RT_LAUNCH(C, P, S) hipLaunchKernelGGL((trace_sweep_kernel<C, P, S>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats)
+#define RT_LAUNCH(C, P, S)                                                                                          \
+    do {                                                                                                            \
+        if (lds_bytes > 48 * 1024) {                                                                                \
+            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S>,                           \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
+            if (e_ != hipSuccess) return e_;                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
+    } while (0)
     if (chunked) {
         if (stats) RT_LAUNCH(true, true, true); else RT_LAUNCH(true, true, false);
     } else if (compact) {
