@@ -145,6 +145,11 @@ void rt_destroy(rt_context *ctx);
  * (main.cpp:21-63).  May be called again between renders (camera sweeps). */
 int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n_objs, const rt_camera *cam);
 
+/* Replaces only pCamera (main.cpp:19): a camera sweep keeps the uploaded object list and changes
+ * the camera between renders without touching the device copy of the scene.  Ordered after the
+ * renders already enqueued (the camera travels with each launch). */
+int rt_set_camera(rt_context *ctx, const rt_camera *cam);
+
 /* Replaces DrawScene (main.cpp:190-228).  Returns after the frame is complete on the device, so
  * host-side chrono timing around it compares with the reference's timing (main.cpp:246-253). */
 int rt_render(rt_context *ctx, const rt_render_params *params);
@@ -152,6 +157,12 @@ int rt_render(rt_context *ctx, const rt_render_params *params);
 /* Replaces the PutPixel side effects of DrawScene: copies rows [row_begin,row_end) of the last
  * render into a caller-allocated buffer (dst_bytes >= rows * width * bytes-per-pixel). */
 int rt_download_framebuffer(rt_context *ctx, void *dst, size_t dst_bytes, int32_t format);
+
+/* Device-side half of the 24-bit download formats: enqueues the RGBA8 -> RT_FMT_RGB8 /
+ * RT_FMT_BMP_BODY packing of the last render's band into caller-owned DEVICE memory (dst_bytes >=
+ * the packed size rounded up to 4), so that a pipeline can copy the BMP file body straight out of
+ * the GPU (replaces WriteBitmap's pixel loop, writebitmap.h:161-178).  Does not wait. */
+int rt_pack_framebuffer(rt_context *ctx, int32_t format, void *device_dst, size_t dst_bytes);
 
 /* Device pointer of an output plane of the last render (band rows only, row_begin first), for
  * device-side assembly (RCCL gather) without a host round trip.  Valid until the next
@@ -200,6 +211,9 @@ int rt_split_bands(const float *row_cost, int32_t height, int32_t n, int32_t *bo
 /* BMP file exactly as WriteBitmap produces it (writebitmap.h:88-182) from Bitmap::pData-layout
  * rgb8, with buffered rows instead of one fprintf per byte. */
 int rt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
+/* The 54 header bytes of that file (writebitmap.h:90-155); header + an RT_FMT_BMP_BODY download is
+ * the complete file. */
+int rt_bmp_header(int32_t width, int32_t height, uint8_t out[54]);
 
 #ifdef __cplusplus
 }

@@ -57,10 +57,10 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_upload_scene", "rt_render", "rt_download_framebuffer",
-    "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
+    "rt_pack_framebuffer", "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
     "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
-    "rt_make_scene", "rt_split_bands", "rt_write_bmp",
+    "rt_make_scene", "rt_split_bands", "rt_write_bmp", "rt_bmp_header",
 ]
 
 
@@ -75,10 +75,12 @@ def _load():
     lib.rt_destroy.argtypes = [vp]
     lib.rt_destroy.restype = None
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Object), i32, C.POINTER(Camera)]
+    lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_sync.argtypes = [vp]
     lib.rt_download_framebuffer.argtypes = [vp, vp, C.c_size_t, i32]
+    lib.rt_pack_framebuffer.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rt_framebuffer_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rt_bind_framebuffer.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
@@ -93,6 +95,7 @@ def _load():
     lib.rt_make_scene.restype = i32
     lib.rt_split_bands.argtypes = [f32p, i32, i32, C.POINTER(i32)]
     lib.rt_write_bmp.argtypes = [C.c_char_p, i32, i32, C.POINTER(C.c_uint8)]
+    lib.rt_bmp_header.argtypes = [i32, i32, C.POINTER(C.c_uint8)]
     return lib
 
 
@@ -148,6 +151,18 @@ def write_bmp(path, rgb8):
         raise RtError(rc, "rt_write_bmp")
 
 
+def bmp_header(width, height):
+    out = (C.c_uint8 * 54)()
+    rc = lib.rt_bmp_header(width, height, out)
+    if rc:
+        raise RtError(rc, "rt_bmp_header")
+    return bytes(out)
+
+
+def bmp_body_bytes(width, rows):
+    return ((width * 3 + 3) & ~3) * rows
+
+
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
                   mode=RT_MODE_EXACT, stats=False):
     p = RenderParams()
@@ -191,6 +206,9 @@ class Context:
     def upload_scene(self, objs, cam):
         self._check(lib.rt_upload_scene(self._h, objs, len(objs), C.byref(cam)))
 
+    def set_camera(self, cam):
+        self._check(lib.rt_set_camera(self._h, C.byref(cam)))
+
     def render(self, params, wait=True):
         fn = lib.rt_render if wait else lib.rt_render_async
         self._check(fn(self._h, C.byref(params)))
@@ -209,6 +227,9 @@ class Context:
 
     def bind_framebuffer(self, plane, ptr, nbytes):
         self._check(lib.rt_bind_framebuffer(self._h, plane, C.c_void_p(ptr), nbytes))
+
+    def pack_framebuffer(self, fmt, device_ptr, nbytes):
+        self._check(lib.rt_pack_framebuffer(self._h, fmt, C.c_void_p(device_ptr), nbytes))
 
     def device_ptr(self, plane):
         p, n = C.c_void_p(), C.c_size_t()

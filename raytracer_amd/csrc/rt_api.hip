@@ -39,6 +39,8 @@ struct rt_context {
     bool have_frame = false;
     int last_outputs = 0;
 
+    void *pack_buf = nullptr;         // staging for the 24-bit download formats
+    size_t pack_bytes = 0;
     RtStatsDev *stats_dev = nullptr;
     rt_stats stats = {};
     bool stats_pending = false;
@@ -90,6 +92,55 @@ static int drain_events(rt_context *ctx, bool block)
         ctx->ev_pending.pop_front();
     }
     return RT_OK;
+}
+
+// ---- RGBA8 -> 24-bit packing on the device ---------------------------------------------------
+// RT_FMT_RGB8: Bitmap::pData (writebitmap.h:5-17), r,g,b per pixel, rows top-down, no padding.
+// RT_FMT_BMP_BODY: what WriteBitmap emits after its header (writebitmap.h:161-178): rows bottom-up,
+// b,g,r per pixel, each row padded with zeros to a multiple of 4 bytes.
+// One thread produces one output dword (4 consecutive bytes), so stores are coalesced.
+static size_t packed_bytes(const RtFrameDev &fr, int format)
+{
+    const size_t w = (size_t)fr.width, rows = (size_t)(fr.row_end - fr.row_begin);
+    const size_t stride = format == RT_FMT_BMP_BODY ? ((w * 3 + 3) & ~(size_t)3) : w * 3;
+    return stride * rows;
+}
+
+__global__ __launch_bounds__(256) void pack_rgb24_kernel(const uint32_t *__restrict__ rgba, uint32_t *__restrict__ out,
+                                                         int width, int rows, int bmp_body, unsigned n_dwords)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_dwords) return;
+    uint32_t word = 0;
+    if (bmp_body) {
+        const unsigned stride_dw = ((unsigned)width * 3u + 3u) >> 2;
+        const unsigned row = j / stride_dw, col = (j - row * stride_dw) * 4u;       // byte column in the padded row
+        const uint32_t *src = rgba + (size_t)(rows - 1 - (int)row) * (size_t)width;  // bottom-up
+#pragma unroll
+        for (unsigned b = 0; b < 4; b++) {
+            const unsigned byte = col + b, px = byte / 3u, ch = byte - px * 3u;
+            if (px < (unsigned)width) word |= ((src[px] >> (8u * (2u - ch))) & 0xffu) << (8u * b);   // b,g,r
+        }
+    } else {
+        const size_t total = (size_t)width * (size_t)rows;
+#pragma unroll
+        for (unsigned b = 0; b < 4; b++) {
+            const size_t byte = (size_t)j * 4u + b, px = byte / 3u;
+            const unsigned ch = (unsigned)(byte - px * 3u);
+            if (px < total) word |= ((rgba[px] >> (8u * ch)) & 0xffu) << (8u * b);                     // r,g,b
+        }
+    }
+    out[j] = word;
+}
+
+static hipError_t launch_pack(const RtFrameDev &fr, const uint32_t *rgba, uint32_t *out, int format, hipStream_t stream)
+{
+    const size_t n_dwords = (packed_bytes(fr, format) + 3) / 4;
+    if (n_dwords == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n_dwords + 255) / 256);
+    hipLaunchKernelGGL(pack_rgb24_kernel, dim3(blocks), dim3(256), 0, stream, rgba, out, fr.width,
+                       fr.row_end - fr.row_begin, format == RT_FMT_BMP_BODY ? 1 : 0, (unsigned)n_dwords);
+    return hipGetLastError();
 }
 
 static int take_event(rt_context *ctx, hipEvent_t *out)
@@ -146,6 +197,7 @@ void rt_destroy(rt_context *ctx)
     for (int i = 0; i < 2; i++)
         if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
     if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+    if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -245,6 +297,15 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_emit = (int32_t)emit.size();
     ctx->cam = *cam;
     ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context *ctx, const rt_camera *cam)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!cam) return fail(ctx, RT_ERR_INVALID_ARG, "rt_set_camera: cam NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_set_camera: no scene uploaded");
+    ctx->cam = *cam;          // passed by value with every launch: nothing on the device changes
     return RT_OK;
 }
 
@@ -444,30 +505,36 @@ int rt_download_framebuffer(rt_context *ctx, void *dst, size_t dst_bytes, int32_
     }
     if (format != RT_FMT_RGB8 && format != RT_FMT_BMP_BODY)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_download_framebuffer: unknown format %d", format);
-    const size_t pad = format == RT_FMT_BMP_BODY ? (4 - (w * 3) % 4) % 4 : 0;
-    const size_t stride = w * 3 + pad, need = stride * rows;
+    const size_t need = packed_bytes(fr, format);
     if (dst_bytes < need) return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_download_framebuffer: need %zu bytes, got %zu", need, dst_bytes);
-    std::vector<uint32_t> tmp(px ? px : 1);
-    RT_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->cur_plane[0], px * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint8_t *out = (uint8_t *)dst;
-    for (size_t r = 0; r < rows; r++) {
-        const uint32_t *src = tmp.data() + r * w;
-        if (format == RT_FMT_RGB8) {                       // Bitmap::pData, writebitmap.h:67-70
-            uint8_t *o = out + r * stride;
-            for (size_t x = 0; x < w; x++) {
-                uint32_t v = src[x];
-                o[3 * x] = (uint8_t)v; o[3 * x + 1] = (uint8_t)(v >> 8); o[3 * x + 2] = (uint8_t)(v >> 16);
-            }
-        } else {                                           // writebitmap.h:161-178: bottom-up, b,g,r, padded
-            uint8_t *o = out + (rows - 1 - r) * stride;
-            for (size_t x = 0; x < w; x++) {
-                uint32_t v = src[x];
-                o[3 * x] = (uint8_t)(v >> 16); o[3 * x + 1] = (uint8_t)(v >> 8); o[3 * x + 2] = (uint8_t)v;
-            }
-            for (size_t k = 0; k < pad; k++) o[3 * w + k] = 0;
-        }
+    if (need == 0) return RT_OK;
+    // pack on the device (3 bytes per pixel leave the GPU instead of 4, and no host loop), then one copy
+    const size_t staged = (need + 3) & ~(size_t)3;
+    if (ctx->pack_bytes < staged) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pack_buf) RT_HIP(ctx, hipFree(ctx->pack_buf));
+        ctx->pack_buf = nullptr;
+        ctx->pack_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->pack_buf, staged));
+        ctx->pack_bytes = staged;
     }
+    RT_HIP(ctx, launch_pack(fr, (const uint32_t *)ctx->cur_plane[0], (uint32_t *)ctx->pack_buf, format, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(dst, ctx->pack_buf, need, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_pack_framebuffer(rt_context *ctx, int32_t format, void *device_dst, size_t dst_bytes)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!device_dst || ((uintptr_t)device_dst & 3)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_pack_framebuffer: dst NULL or not 4-byte aligned");
+    if (!ctx->have_frame || !ctx->cur_plane[0]) return fail(ctx, RT_ERR_NO_FRAME, "rt_pack_framebuffer: no RGBA8 frame rendered");
+    if (format != RT_FMT_RGB8 && format != RT_FMT_BMP_BODY)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_pack_framebuffer: format must be RT_FMT_RGB8 or RT_FMT_BMP_BODY");
+    const size_t need = (packed_bytes(ctx->frame, format) + 3) & ~(size_t)3;
+    if (dst_bytes < need) return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_pack_framebuffer: need %zu bytes, got %zu", need, dst_bytes);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, launch_pack(ctx->frame, (const uint32_t *)ctx->cur_plane[0], (uint32_t *)device_dst, format, ctx->stream));
     return RT_OK;
 }
 

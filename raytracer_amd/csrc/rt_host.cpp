@@ -206,6 +206,20 @@ int rt_split_bands(const float *row_cost, int32_t height, int32_t n, int32_t *bo
     return RT_OK;
 }
 
+// The 54 header bytes WriteBitmap emits (writebitmap.h:90-155) for a width x height image.
+int rt_bmp_header(int32_t width, int32_t height, uint8_t out[54])
+{
+    if (!out || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
+    const size_t stride = ((size_t)width * 3 + 3) & ~(size_t)3;
+    const uint32_t body = (uint32_t)(stride * (size_t)height);
+    const uint32_t words[13] = {body + 54u, 0u, 54u, 40u, (uint32_t)width, (uint32_t)height,
+                                1u | (24u << 16), 0u, body, 0u, 0u, 0u, 0u};
+    out[0] = 'B'; out[1] = 'M';
+    for (int i = 0; i < 13; i++)
+        for (int b = 0; b < 4; b++) out[2 + 4 * i + b] = (uint8_t)(words[i] >> (8 * b));
+    return RT_OK;
+}
+
 // WriteBitmap, writebitmap.h:88-182: identical bytes, one fwrite per row instead of one fprintf
 // per byte (which costs ~100 M calls at 8K).
 int rt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *rgb8)
@@ -213,13 +227,8 @@ int rt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t 
     if (!path || !rgb8 || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
     int pad = (4 - (width * 3) % 4) % 4;
     size_t stride = (size_t)width * 3 + (size_t)pad;
-    uint32_t body = (uint32_t)(stride * (size_t)height);
-    const uint32_t words[13] = {body + 54u, 0u, 54u, 40u, (uint32_t)width, (uint32_t)height,
-                                1u | (24u << 16), 0u, body, 0u, 0u, 0u, 0u};
     uint8_t head[54];
-    head[0] = 'B'; head[1] = 'M';
-    for (int i = 0; i < 13; i++)
-        for (int b = 0; b < 4; b++) head[2 + 4 * i + b] = (uint8_t)(words[i] >> (8 * b));
+    rt_bmp_header(width, height, head);
     FILE *f = fopen(path, "wb");
     if (!f) return RT_ERR_INVALID_ARG;
     bool ok = fwrite(head, 1, sizeof head, f) == sizeof head;
