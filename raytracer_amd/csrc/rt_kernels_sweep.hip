@@ -336,7 +336,7 @@ __device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc,
 
 // COMPACT: pack the live hit points of the workgroup before every bounce sweep (pays off once a
 // sweep is long enough to dwarf three barriers: scenes of more than a few dozen spheres).
-template <bool CHUNKED, bool COMPACT, bool STATS>
+template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
@@ -366,9 +366,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
     if (!CHUNKED) stage<false>(sc, lds, cap, 0, (sc.n_spheres + 1) >> 1, false, cam_pos);
 
     // one record per path segment, read back deepest-first (runtime-indexed -> private memory)
-    float rec_pos[RT_MAX_LEVELS][3], rec_n[RT_MAX_LEVELS][3], rec_r[RT_MAX_LEVELS][3];
-    int rec_mat[RT_MAX_LEVELS];
-    unsigned long long rec_lit[RT_MAX_LEVELS], rec_alt[RT_MAX_LEVELS];
+    // LEVELS >= max_depth + 1 (the launcher picks the smallest instantiation that fits: the
+    // footprint of this private memory, times 262 144 resident lanes, decides whether the record
+    // traffic stays in the 256 MB Infinity Cache or goes to HBM)
+    float rec_pos[LEVELS][3], rec_n[LEVELS][3], rec_r[LEVELS][3];
+    int rec_mat[LEVELS];
+    unsigned long long rec_lit[LEVELS], rec_alt[LEVELS];
 
     unsigned n_refl = 0, n_shadow = 0, n_hits = 0, n_lit = 0;
     V3 color = v3(0.0f, 0.0f, 0.0f);
@@ -609,14 +612,19 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const size_t lds_bytes = (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     const bool compact = n_pairs >= 24;
-#define RT_LAUNCH(C, P, S)                                                                                          \
+#define RT_LAUNCH_L(C, P, S, L)                                                                                         \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \
-            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S>,                           \
+            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S, L>,                           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e_ != hipSuccess) return e_;                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
+        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S, L>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
+    } while (0)
+#define RT_LAUNCH(C, P, S)                                      \
+    do {                                                        \
+        if (frame.max_depth < 6) RT_LAUNCH_L(C, P, S, 6);       \
+        else RT_LAUNCH_L(C, P, S, RT_MAX_LEVELS);               \
     } while (0)
     if (chunked) {
         if (stats) RT_LAUNCH(true, true, true); else RT_LAUNCH(true, true, false);
@@ -626,5 +634,6 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
         if (stats) RT_LAUNCH(false, false, true); else RT_LAUNCH(false, false, false);
     }
 #undef RT_LAUNCH
+#undef RT_LAUNCH_L
     return hipGetLastError();
 }
