@@ -31,14 +31,14 @@ FLOP_PER_SPHERE_TEST = 15       # 3 sub + 5 (dot) + 5 (dot) + mu
 FLOP_PER_PLANE_TEST = 5
 
 
-def cpu_baseline(capi, width, height, depth, spp, kind):
+def cpu_baseline(capi, width, height, depth, spp, kind, offsets=None):
     """Times the CPU oracle (a port of the reference loop) on a bounded sample of the workload:
     the same scene and camera at 1/2 resolution per axis."""
     from oracle import oracle_lib
     lw, lh = width // 2, height // 2
     objs, cam = capi.make_scene(kind, lw, lh)
     threads = max(1, min(16, os.cpu_count() or 1))
-    p = capi.render_params(lw, lh, depth, spp)
+    p = capi.render_params(lw, lh, depth, spp, offsets=offsets)
     t0 = time.perf_counter()
     _, _, st = oracle_lib.render(objs, cam, p, threads=threads, want_rgb8=True, want_f32=False, want_stats=True)
     dt = time.perf_counter() - t0
@@ -106,15 +106,18 @@ def main():
     ctx.bind_framebuffer(capi.RT_OUT_RGBA8, band.data_ptr(), band.numel() * 4)
     frame = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
 
+    # 1 and 4 spp use the reference's fixed pattern; other counts the stratified pattern of config 3
+    offsets = None if args.spp in (1, 4) else capi.stratified_offsets(args.spp)
+
     # ray census of this rank's band (untimed)
-    ctx.render(capi.render_params(W, H, args.depth, args.spp, rows=(y0, y1), mode=mode, stats=True))
+    ctx.render(capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, stats=True))
     st = ctx.stats()
     n_sph = sum(1 for o in objs if o.type == capi.RT_OBJ_SPHERE)
     n_pl = len(objs) - n_sph
     my_rays = st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
     my_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
 
-    params = capi.render_params(W, H, args.depth, args.spp, rows=(y0, y1), mode=mode)
+    params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -192,7 +195,7 @@ def main():
         }
         out["config"]["frame_crc"] = int(frame.to(torch.int64).sum().item() & 0xFFFFFFFF)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind)
+            out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind, offsets)
         print(json.dumps(out), flush=True)
 
     ctx.set_stream(0)

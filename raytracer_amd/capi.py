@@ -163,6 +163,22 @@ def bmp_body_bytes(width, rows):
     return ((width * 3 + 3) & ~3) * rows
 
 
+def stratified_offsets(spp=16, seed=0x16A11CE):
+    """Config 3's sample pattern: sqrt(spp) x sqrt(spp) stratified offsets from the
+    scene generators' LCG, one pattern shared by every pixel like the reference's static pattern
+    (raytracer_cpp/main.cpp:202)."""
+    g = int(round(spp ** 0.5))
+    assert g * g == spp
+    s, out = seed, []
+    for i in range(spp):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        u = np.float32(s >> 8) * np.float32(2.0 ** -24)
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        v = np.float32(s >> 8) * np.float32(2.0 ** -24)
+        out.append(((np.float32(i % g) + u) / np.float32(g), (np.float32(i // g) + v) / np.float32(g)))
+    return np.asarray(out, dtype=np.float32)
+
+
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
                   mode=RT_MODE_EXACT, stats=False):
     p = RenderParams()

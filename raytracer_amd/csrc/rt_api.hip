@@ -405,10 +405,10 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     { int rc = take_event(ctx, &ev0); if (rc) return rc; rc = take_event(ctx, &ev1); if (rc) return rc; }
     RT_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     if (px > 0) {
-        // One kernel serves both modes: it is bit-exact (RT_MODE_EXACT), which is a superset of
-        // RT_MODE_FAST's 1e-4 contract.
+        // RT_MODE_FAST: same sweeps, shading by throughput accumulation (no per-segment records).
+        // The straight-transcription kernel has only the exact formulation.
         if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
-        else RT_HIP(ctx, rt_launch_trace_sweep(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
+        else RT_HIP(ctx, rt_launch_trace_sweep(ctx->scene, ctx->cam, fr, smp, sdev, p->mode == RT_MODE_FAST, ctx->stream));
     }
     RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     ctx->ev_pending.emplace_back(ev0, ev1);

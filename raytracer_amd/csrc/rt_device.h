@@ -69,7 +69,7 @@ struct RtSamples {
 
 // kernel launchers
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
-                                 const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
+                                 const RtSamples &samples, RtStatsDev *stats, bool fast, hipStream_t stream);
 hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
 

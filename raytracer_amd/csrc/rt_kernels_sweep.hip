@@ -49,6 +49,9 @@ constexpr int kMaxK = 5;                       // rays swept together
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4
 #endif
+#ifndef RT_WAVES_PER_SIMD_SMALL
+#define RT_WAVES_PER_SIMD_SMALL 2                // scenes of a few spheres: registers over occupancy
+#endif
 constexpr float kRelKeep = 1.0f - 0x1p-17f;    // filter: uu * (1 - 2^-17)
 constexpr float kAbsScale = 0x1p-19f;          // filter: 2^-19 * (|pos|^2 + 2^-13)
 constexpr float kAbsFloor = 0x1p-13f;
@@ -334,10 +337,56 @@ __device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc,
     }
 }
 
+// The emitter loop of TraceRay (main.cpp:112-184) for the emitters whose shadow ray came back lit:
+// adds each light's contribution to `out` in list order.  FASTPOW: x^10 by four float multiplies
+// instead of the double-precision pow the reference calls (RT_MODE_FAST only).
+template <bool STATS, bool FASTPOW>
+__device__ __forceinline__ V3 add_lights(const RtSceneDev &sc, V3 out, V3 pos, V3 n, V3 refl, const rt_material &m,
+                                         unsigned long long lit, unsigned long long alt, unsigned &n_lit)
+{
+    for (int e = 0; e < sc.n_emit; e++) {                                    // main.cpp:112
+        if (!((lit >> e) & 1ull)) continue;
+        const RtEmitterDev em = sc.emit[e];
+        const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);            // main.cpp:114
+        float diffuse = dot(n, edir);                                        // main.cpp:162
+        float spec = 0.0f;
+        if (diffuse > 0.0f) {
+            spec = dot(refl, edir);                                          // main.cpp:166
+            if (spec > 0.0f) {
+                if (FASTPOW) {
+                    const float s2 = spec * spec, s4 = s2 * s2;
+                    spec = (s4 * s4) * s2;
+                } else {
+                    spec = pow10_like_libm(spec);                            // main.cpp:169
+                }
+                spec = 0.0f < spec ? spec : 0.0f;                            // main.cpp:170
+            } else {
+                spec = 0.0f;
+            }
+        } else {
+            diffuse = 0.0f;
+        }
+        if (STATS) n_lit++;
+        const float *ee = sc.mats[2 * em.id + (int)((alt >> e) & 1ull)].emissive;
+        const V3 l = (v3(ee[0], ee[1], ee[2]) * v3(m.albedo[0], m.albedo[1], m.albedo[2])) * diffuse +
+                     v3(m.specular[0], m.specular[1], m.specular[2]) * spec;   // main.cpp:183
+        out = out + l;
+    }
+    return out;
+}
+
 // COMPACT: pack the live hit points of the workgroup before every bounce sweep (pays off once a
 // sweep is long enough to dwarf three barriers: scenes of more than a few dozen spheres).
-template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS>
-__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
+//
+// FAST (RT_MODE_FAST): north_star's formulation -- no per-segment records.  The recursion
+//     out_l = (out_{l+1} * r_l + L_l) * (1 - r_l) + e_l                    (main.cpp:109-186)
+// is unrolled top-down with a per-lane throughput T_0 = 1, T_{l+1} = T_l * r_l * (1 - r_l):
+//     out_0 = sum_l T_l * (L_l * (1 - r_l) + e_l)  [+ T_{last+1} * 0.1 when the last ray misses],
+// so a segment is shaded as soon as its shadow mask is known and nothing is kept in private memory.
+// Same hits, same lights; the sum associates differently, so radiance agrees with the reference to
+// rounding (<= 1e-5 relative, tested at 1e-4), not bit for bit.
+template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS, bool FAST>
+__global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_SMALL) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
     extern __shared__ float4 lds[];
@@ -369,9 +418,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
     // LEVELS >= max_depth + 1 (the launcher picks the smallest instantiation that fits: the
     // footprint of this private memory, times 262 144 resident lanes, decides whether the record
     // traffic stays in the 256 MB Infinity Cache or goes to HBM)
-    float rec_pos[LEVELS][3], rec_n[LEVELS][3], rec_r[LEVELS][3];
-    int rec_mat[LEVELS];
-    unsigned long long rec_lit[LEVELS], rec_alt[LEVELS];
+    constexpr int kRec = FAST ? 1 : LEVELS;
+    float rec_pos[kRec][3], rec_n[kRec][3], rec_r[kRec][3];
+    int rec_mat[kRec];
+    unsigned long long rec_lit[kRec], rec_alt[kRec];
 
     unsigned n_refl = 0, n_shadow = 0, n_hits = 0, n_lit = 0;
     V3 color = v3(0.0f, 0.0f, 0.0f);
@@ -400,20 +450,20 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
         }
         bool miss_tail = in_image && !alive;                                 // main.cpp:90-93
         int nlev = 0;
+        float tp = 1.0f;                                                     // FAST: throughput
+        V3 acc = miss_tail ? v3(0.1f, 0.1f, 0.1f) : v3(0.0f, 0.0f, 0.0f);    // FAST: radiance so far
 
         // ---- forward: hit chain + shadow masks, live hit points compacted across the workgroup ----
         for (int depth = 0; depth <= fr.max_depth; depth++) {
-            V3 pos = cam_pos, refl = v3(0, 0, 0);
+            V3 pos = cam_pos, refl = v3(0, 0, 0), n = v3(0, 0, 0);
             bool want_refl = false;
-            int my_slot = 0;
+            int my_slot = 0, mat = 0;
             if (COMPACT) __syncthreads();     // previous level's results are consumed, counters are reset
             else if (!block_any<CHUNKED>(alive)) break;
             {
                 if (alive) {
                     if (STATS) n_hits++;
                     pos = seg.o + seg.d * seg.dist;                          // main.cpp:94
-                    V3 n;
-                    int mat;
                     if (seg.slot >= 0) {
                         const float4 A = sc.pairs[2 * (seg.slot >> 1)], B = sc.pairs[2 * (seg.slot >> 1) + 1];
                         const V3 c = (seg.slot & 1) ? v3(A.y, A.w, B.y) : v3(A.x, A.z, B.x);
@@ -425,10 +475,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
                         mat = 2 * seg.id + (checker_white(pos) ? 0 : 1);     // sceneobjects.h:106-115
                     }
                     refl = normalize(reflect(seg.d, n));                     // main.cpp:100
-                    rec_pos[nlev][0] = pos.x; rec_pos[nlev][1] = pos.y; rec_pos[nlev][2] = pos.z;
-                    rec_n[nlev][0] = n.x; rec_n[nlev][1] = n.y; rec_n[nlev][2] = n.z;
-                    rec_r[nlev][0] = refl.x; rec_r[nlev][1] = refl.y; rec_r[nlev][2] = refl.z;
-                    rec_mat[nlev] = mat;
+                    if constexpr (!FAST) {
+                        rec_pos[nlev][0] = pos.x; rec_pos[nlev][1] = pos.y; rec_pos[nlev][2] = pos.z;
+                        rec_n[nlev][0] = n.x; rec_n[nlev][1] = n.y; rec_n[nlev][2] = n.z;
+                        rec_r[nlev][0] = refl.x; rec_r[nlev][1] = refl.y; rec_r[nlev][2] = refl.z;
+                        rec_mat[nlev] = mat;
+                    }
                     want_refl = depth < fr.max_depth && sc.mats[mat].reflectance > 0.0f;   // main.cpp:103
                     if (want_refl) n_refl++;
                     n_shadow += sc.n_emit;
@@ -518,9 +570,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
                 next.slot = INT_MIN;
             }
             if (alive) {
-                rec_lit[nlev] = lit;
-                rec_alt[nlev] = alt;
-                nlev++;
+                if constexpr (FAST) {
+                    const rt_material m = sc.mats[mat];
+                    V3 local = add_lights<STATS, true>(sc, v3(0.0f, 0.0f, 0.0f), pos, n, refl, m, lit, alt, n_lit);
+                    local = local * (1.f - m.reflectance) + v3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                    acc = acc + local * tp;
+                    tp = tp * (m.reflectance * (1.f - m.reflectance));
+                } else {
+                    rec_lit[nlev] = lit;
+                    rec_alt[nlev] = alt;
+                    nlev++;
+                }
                 if (want_refl) {
                     const int hit_slot = next.slot;
                     seg.o = pos + refl * 0.001f;                             // main.cpp:108
@@ -530,6 +590,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
                     seg.id = next.id;
                     alive = hit_slot != INT_MIN;
                     miss_tail = !alive;
+                    if (FAST && !alive) acc = acc + v3(0.1f, 0.1f, 0.1f) * tp;   // main.cpp:92 through the chain
                 } else {
                     alive = false;
                 }
@@ -539,6 +600,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
         // ---- backward: shade deepest segment first (main.cpp:109-187) ----
         V3 child = v3(0.1f, 0.1f, 0.1f);           // what a missing ray returns (main.cpp:92)
         bool has_child = miss_tail;
+        if constexpr (FAST) child = acc;
         for (int lev = nlev - 1; lev >= 0; lev--) {
             const V3 pos = v3(rec_pos[lev][0], rec_pos[lev][1], rec_pos[lev][2]);
             const V3 n = v3(rec_n[lev][0], rec_n[lev][1], rec_n[lev][2]);
@@ -547,29 +609,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
             const unsigned long long lit = rec_lit[lev], alt = rec_alt[lev];
             V3 out = v3(0.0f, 0.0f, 0.0f);
             if (has_child) out = child * m.reflectance;                      // main.cpp:109
-            for (int e = 0; e < sc.n_emit; e++) {                            // main.cpp:112
-                if (!((lit >> e) & 1ull)) continue;
-                const RtEmitterDev em = sc.emit[e];
-                const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);    // main.cpp:114
-                float diffuse = dot(n, edir);                                // main.cpp:162
-                float spec = 0.0f;
-                if (diffuse > 0.0f) {
-                    spec = dot(refl, edir);                                  // main.cpp:166
-                    if (spec > 0.0f) {
-                        spec = pow10_like_libm(spec);                        // main.cpp:169
-                        spec = 0.0f < spec ? spec : 0.0f;                    // main.cpp:170
-                    } else {
-                        spec = 0.0f;
-                    }
-                } else {
-                    diffuse = 0.0f;
-                }
-                if (STATS) n_lit++;
-                const float *ee = sc.mats[2 * em.id + (int)((alt >> e) & 1ull)].emissive;
-                const V3 l = (v3(ee[0], ee[1], ee[2]) * v3(m.albedo[0], m.albedo[1], m.albedo[2])) * diffuse +
-                             v3(m.specular[0], m.specular[1], m.specular[2]) * spec;   // main.cpp:183
-                out = out + l;
-            }
+            out = add_lights<STATS, false>(sc, out, pos, n, refl, m, lit, alt, n_lit);
             out = out * (1.f - m.reflectance);                               // main.cpp:185
             out = out + v3(m.emissive[0], m.emissive[1], m.emissive[2]);     // main.cpp:186
             child = out;
@@ -600,7 +640,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void trace_sweep_kernel(
 } // namespace
 
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
-                                 const RtSamples &samples, RtStatsDev *stats, hipStream_t stream)
+                                 const RtSamples &samples, RtStatsDev *stats, bool fast, hipStream_t stream)
 {
     const int rows = frame.row_end - frame.row_begin;
     const int tiles = ((frame.width + 7) / 8) * ((rows + 7) / 8);
@@ -612,19 +652,20 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const size_t lds_bytes = (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     const bool compact = n_pairs >= 24;
-#define RT_LAUNCH_L(C, P, S, L)                                                                                         \
+#define RT_LAUNCH_L(C, P, S, L, F)                                                                                       \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \
-            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S, L>,                           \
+            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S, L, F>,                           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e_ != hipSuccess) return e_;                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S, L>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
+        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S, L, F>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
     } while (0)
 #define RT_LAUNCH(C, P, S)                                      \
     do {                                                        \
-        if (frame.max_depth < 6) RT_LAUNCH_L(C, P, S, 6);       \
-        else RT_LAUNCH_L(C, P, S, RT_MAX_LEVELS);               \
+        if (fast) RT_LAUNCH_L(C, P, S, 1, true);                       \
+        else if (frame.max_depth < 6) RT_LAUNCH_L(C, P, S, 6, false);  \
+        else RT_LAUNCH_L(C, P, S, RT_MAX_LEVELS, false);               \
     } while (0)
     if (chunked) {
         if (stats) RT_LAUNCH(true, true, true); else RT_LAUNCH(true, true, false);
