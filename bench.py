@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--sweep", default="flat", choices=["flat", "grouped"],
+                    help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 16 are skipped when missed")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
@@ -89,6 +91,7 @@ def main():
 
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
     mode = capi.RT_MODE_EXACT if args.mode == "exact" else capi.RT_MODE_FAST
+    sweep = capi.RT_SWEEP_GROUPED if args.sweep == "grouped" else capi.RT_SWEEP_FLAT
     W, H = args.width, args.height
     objs, cam = capi.make_scene(kind, W, H)
     ctx = capi.Context(local)
@@ -110,14 +113,14 @@ def main():
     offsets = None if args.spp in (1, 4) else capi.stratified_offsets(args.spp)
 
     # ray census of this rank's band (untimed)
-    ctx.render(capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, stats=True))
+    ctx.render(capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, stats=True, sweep=sweep))
     st = ctx.stats()
     n_sph = sum(1 for o in objs if o.type == capi.RT_OBJ_SPHERE)
     n_pl = len(objs) - n_sph
     my_rays = st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
     my_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
 
-    params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode)
+    params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=sweep)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -181,9 +184,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.scene}: {len(objs)} objects ({n_sph} spheres, {st['n_emitters']} emissive), "
-                                   f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}",
+                                   f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}, sweep {args.sweep}",
                        "rays_per_frame": int(rays), "bands": bounds,
-                       "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit")},
+                       "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
+                                                                         "sphere_tests", "sphere_tests_run", "group_tests_run")},
                        "parallelism": f"row-bands x{world}" + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,

@@ -105,6 +105,14 @@ enum {
     RT_MODE_FAST = 1    /* FMA contraction + throughput accumulator; radiance within 1e-4 rel    */
 };
 
+/* How a ray visits the sphere list.  Both give the same image, bit for bit. */
+enum {
+    RT_SWEEP_FLAT = 0,   /* every ray is tested against every sphere, list streamed through LDS:
+                            FindNearestObject's loop (main.cpp:65-82) as it stands                 */
+    RT_SWEEP_GROUPED = 1 /* spheres are grouped (16 per group, Morton order) at upload; a ray whose
+                            line misses a group's bounding sphere skips the group                  */
+};
+
 typedef struct rt_render_params {
     int32_t width;          /* pixel loop bounds (ImageWidth / ImageHeight, main.cpp:12-13)       */
     int32_t height;
@@ -117,6 +125,7 @@ typedef struct rt_render_params {
     int32_t outputs;        /* RT_OUT_* flags; 0 = RT_OUT_RGBA8                                   */
     int32_t mode;           /* RT_MODE_*                                                          */
     int32_t collect_stats;  /* non-zero: count rays/tests in-kernel (slower; rt_get_stats)        */
+    int32_t sweep;          /* RT_SWEEP_*                                                         */
 } rt_render_params;
 
 typedef struct rt_stats {
@@ -132,6 +141,9 @@ typedef struct rt_stats {
     double kernel_ms;           /* device time of the last rt_render's trace kernel (HIP events)  */
     double kernel_ms_total;     /* cumulative over every render of this context ...               */
     uint64_t kernels_timed;     /* ... and how many launches that covers                          */
+    uint64_t sphere_tests_run;  /* (ray, sphere) tests the kernel executed: = sphere_tests (+ odd-tail
+                                   padding) for RT_SWEEP_FLAT, fewer for RT_SWEEP_GROUPED            */
+    uint64_t group_tests_run;   /* (ray, group) bounding-sphere tests executed (RT_SWEEP_GROUPED)   */
 } rt_stats;
 
 typedef struct rt_context rt_context;

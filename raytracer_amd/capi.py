@@ -19,6 +19,7 @@ RT_OBJ_SPHERE, RT_OBJ_TILED_PLANE = 0, 1
 RT_OUT_RGBA8, RT_OUT_F32X4 = 1, 2
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
+RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1
 RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
 
 
@@ -46,14 +47,15 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
                 ("spp", C.c_int32), ("sample_offsets", C.POINTER(C.c_float)),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("outputs", C.c_int32),
-                ("mode", C.c_int32), ("collect_stats", C.c_int32)]
+                ("mode", C.c_int32), ("collect_stats", C.c_int32), ("sweep", C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                  "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + \
-               [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("kernels_timed", C.c_uint64)]
+               [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("kernels_timed", C.c_uint64),
+                ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64)]
 
 
 EXPORTS = [
@@ -180,7 +182,7 @@ def stratified_offsets(spp=16, seed=0x16A11CE):
 
 
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
-                  mode=RT_MODE_EXACT, stats=False):
+                  mode=RT_MODE_EXACT, stats=False, sweep=0):
     p = RenderParams()
     p.width, p.height, p.max_depth, p.spp = width, height, max_depth, spp
     keep = None
@@ -190,7 +192,7 @@ def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, ou
         p.sample_offsets = keep.ctypes.data_as(C.POINTER(C.c_float))
     if rows is not None:
         p.row_begin, p.row_end = rows
-    p.outputs, p.mode, p.collect_stats = outputs, mode, int(stats)
+    p.outputs, p.mode, p.collect_stats, p.sweep = outputs, mode, int(stats), sweep
     p._keep = keep  # keep the offsets array alive as long as the struct
     return p
 

@@ -3,6 +3,8 @@
 // every entry point that needs the device fails with an rt_status when HIP is unusable.
 #include "rt_device.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +27,8 @@ struct rt_context {
     // scene
     void *scene_blob = nullptr;       // one allocation holding pairs | geom | sph_id | planes | mats | emit
     size_t scene_blob_bytes = 0;
-    RtSceneDev scene = {};
+    RtSceneDev scene = {};            // flat layout (list order)
+    RtSceneDev scene_grouped = {};    // grouped layout (RT_SWEEP_GROUPED)
     rt_camera cam = {};
     bool have_scene = false;
 
@@ -206,6 +209,162 @@ void rt_destroy(rt_context *ctx)
 
 const char *rt_last_error(rt_context *ctx) { return ctx ? ctx->err : g_create_err; }
 
+// ---- grouped layout (RT_SWEEP_GROUPED) ---------------------------------------------------------
+// Spheres are sorted along a Morton curve through their centres and cut greedily into groups of at
+// most 2*RT_GROUP_PAIRS; a group is closed early when the next sphere would blow its bounding
+// radius past a cap derived from the typical spacing, so a far-away light or a huge sphere ends up
+// in a group of its own instead of inflating its neighbours' bound.
+struct GroupedScene {
+    std::vector<float4> pairs;     // 2 * RT_GROUP_PAIRS * n_groups
+    std::vector<int32_t> ids;      // 2 * RT_GROUP_PAIRS * n_groups (list index, -1 = padding)
+    std::vector<int32_t> slot_of;  // geom index -> slot
+    std::vector<float4> heads;     // 2 * ceil(n_groups / 2)
+    int n_groups = 0;
+};
+
+static uint32_t spread10(uint32_t v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+static void build_groups(const std::vector<float4> &geom, const std::vector<float> &radius,
+                         const std::vector<int32_t> &sph_id, GroupedScene &out)
+{
+    const size_t n = geom.size();
+    const int kMax = 2 * RT_GROUP_PAIRS;
+    out = GroupedScene();
+    out.slot_of.assign(n, -1);
+    if (n == 0) return;
+
+    std::vector<char> finite(n);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < n; i++) {
+        const float c[3] = {geom[i].x, geom[i].y, geom[i].z};
+        finite[i] = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(radius[i]);
+        if (!finite[i]) continue;
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)c[a]); hi[a] = std::max(hi[a], (double)c[a]); }
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> order(n);     // (morton, geom index)
+    for (size_t i = 0; i < n; i++) {
+        uint32_t code = 0xFFFFFFFFu;                          // non-finite spheres go last
+        if (finite[i]) {
+            const float c[3] = {geom[i].x, geom[i].y, geom[i].z};
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++) {
+                const double ext = hi[a] - lo[a];
+                q[a] = ext > 0 ? (uint32_t)std::min(1023.0, (c[a] - lo[a]) / ext * 1024.0) : 0u;
+            }
+            code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+        }
+        order[i] = {code, (uint32_t)i};
+    }
+    std::stable_sort(order.begin(), order.end());
+
+    // typical spacing along the curve (median distance between neighbours) and typical radius
+    std::vector<double> gaps, rads;
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = order[k].second;
+        if (!finite[i]) continue;
+        rads.push_back(std::fabs((double)radius[i]));
+        if (k + 1 < n && finite[order[k + 1].second]) {
+            const size_t j = order[k + 1].second;
+            const double dx = geom[i].x - geom[j].x, dy = geom[i].y - geom[j].y, dz = geom[i].z - geom[j].z;
+            gaps.push_back(std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+    }
+    auto median = [](std::vector<double> &v) {
+        if (v.empty()) return 0.0;
+        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        return v[v.size() / 2];
+    };
+    const double cap = 3.5 * median(gaps) + 2.0 * median(rads);
+
+    struct Group { std::vector<uint32_t> members; double c[3]; double R; };
+    std::vector<Group> groups;
+    auto bound_of = [&](const std::vector<uint32_t> &m, double c[3]) {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t i : m) {
+            const double cc[3] = {geom[i].x, geom[i].y, geom[i].z}, r = std::fabs((double)radius[i]);
+            for (int a = 0; a < 3; a++) { blo[a] = std::min(blo[a], cc[a] - r); bhi[a] = std::max(bhi[a], cc[a] + r); }
+        }
+        for (int a = 0; a < 3; a++) c[a] = 0.5 * (blo[a] + bhi[a]);
+        double R = 0;
+        for (uint32_t i : m) {
+            const double dx = geom[i].x - c[0], dy = geom[i].y - c[1], dz = geom[i].z - c[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)radius[i]));
+        }
+        return R;
+    };
+    std::vector<uint32_t> cur;
+    auto close = [&]() {
+        if (cur.empty()) return;
+        Group g;
+        g.members = cur;
+        g.R = bound_of(cur, g.c);
+        groups.push_back(g);
+        cur.clear();
+    };
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t i = order[k].second;
+        if (!finite[i]) {                   // never hit by anything (dSquared is NaN or r*r is inf): own group
+            close();
+            cur.push_back(i);
+            close();
+            continue;
+        }
+        if ((int)cur.size() == kMax) close();
+        if (!cur.empty()) {
+            std::vector<uint32_t> trial = cur;
+            trial.push_back(i);
+            double c[3];
+            const double R = bound_of(trial, c);
+            if (R > cap + std::fabs((double)radius[i])) close();
+        }
+        cur.push_back(i);
+    }
+    close();
+
+    out.n_groups = (int)groups.size();
+    const float kNoHit = 3.402823466e+38f;
+    out.pairs.assign((size_t)2 * RT_GROUP_PAIRS * groups.size(), make_float4(0.0f, 0.0f, kNoHit, kNoHit));
+    out.ids.assign((size_t)kMax * groups.size(), -1);
+    for (size_t g = 0; g < groups.size(); g++) {
+        for (int p = 0; p < RT_GROUP_PAIRS; p++) out.pairs[2 * (g * RT_GROUP_PAIRS + p)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        std::vector<uint32_t> &m = groups[g].members;
+        std::sort(m.begin(), m.end());      // list order inside a group: most ties resolve by slot order already
+        for (size_t j = 0; j < m.size(); j++) {
+            const size_t slot = g * kMax + j, pr = slot >> 1;
+            const float4 s = geom[m[j]];
+            float4 &A = out.pairs[2 * pr], &B = out.pairs[2 * pr + 1];
+            if (slot & 1) { A.y = s.x; A.w = s.y; B.y = s.z; B.w = -s.w; }
+            else          { A.x = s.x; A.z = s.y; B.x = s.z; B.z = -s.w; }
+            out.ids[slot] = sph_id[m[j]];
+            out.slot_of[m[j]] = (int32_t)slot;
+        }
+    }
+    out.heads.assign(2 * ((groups.size() + 1) / 2), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (size_t g = 0; g < out.heads.size(); g++) {
+        float c[3] = {0.0f, 0.0f, 0.0f}, R = -1.0f;          // odd tail: R < 0 marks "no group"
+        if (g < groups.size()) {
+            for (int a = 0; a < 3; a++) c[a] = (float)groups[g].c[a];
+            // the centre was rounded to float: widen by that displacement, then round the radius up
+            double d2 = 0;
+            for (int a = 0; a < 3; a++) d2 += ((double)c[a] - groups[g].c[a]) * ((double)c[a] - groups[g].c[a]);
+            const double Rd = (groups[g].R + std::sqrt(d2)) * (1.0 + 0x1p-20);
+            R = std::isfinite(Rd) && Rd < 1e37 ? std::nextafterf((float)Rd, INFINITY) : INFINITY;
+            if (!(Rd == Rd)) R = INFINITY;                    // NaN bound: always visit
+        }
+        float4 &A = out.heads[2 * (g >> 1)], &B = out.heads[2 * (g >> 1) + 1];
+        if (g & 1) { A.y = c[0]; A.w = c[1]; B.y = c[2]; B.w = R; }
+        else       { A.x = c[0]; A.z = c[1]; B.x = c[2]; B.z = R; }
+    }
+}
+
 int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_camera *cam)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -213,6 +372,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (n > (1 << 22)) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %d objects > limit %d", n, 1 << 22);
 
     std::vector<float4> geom;
+    std::vector<float> radius;
     std::vector<int32_t> sph_id;
     std::vector<RtPlaneDev> planes;
     std::vector<rt_material> mats((size_t)2 * n);
@@ -226,6 +386,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         if (o.type == RT_OBJ_SPHERE) {
             slot = (int32_t)geom.size();
             geom.push_back(make_float4(o.a[0], o.a[1], o.a[2], o.radius * o.radius));  // sceneobjects.h:71
+            radius.push_back(o.radius);
             sph_id.push_back(k);
             mats[2 * (size_t)k + 1] = o.mat;
             emits = emissive_nonzero(o.mat);
@@ -255,6 +416,9 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         pairs.push_back(make_float4(g0.z, g1.z, -g0.w, -g1.w));
     }
 
+    GroupedScene grp;
+    build_groups(geom, radius, sph_id, grp);
+
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off_pairs = 0;
     size_t off_geom = align(off_pairs + pairs.size() * sizeof(float4));
@@ -262,7 +426,10 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     size_t off_planes = align(off_id + sph_id.size() * sizeof(int32_t));
     size_t off_mats = align(off_planes + planes.size() * sizeof(RtPlaneDev));
     size_t off_emit = align(off_mats + mats.size() * sizeof(rt_material));
-    size_t total = align(off_emit + emit.size() * sizeof(RtEmitterDev)) + 256;
+    size_t off_gpairs = align(off_emit + emit.size() * sizeof(RtEmitterDev));
+    size_t off_gids = align(off_gpairs + grp.pairs.size() * sizeof(float4));
+    size_t off_heads = align(off_gids + grp.ids.size() * sizeof(int32_t));
+    size_t total = align(off_heads + grp.heads.size() * sizeof(float4)) + 256;
 
     std::vector<uint8_t> blob(total, 0);
     if (!pairs.empty()) memcpy(blob.data() + off_pairs, pairs.data(), pairs.size() * sizeof(float4));
@@ -271,6 +438,9 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (!planes.empty()) memcpy(blob.data() + off_planes, planes.data(), planes.size() * sizeof(RtPlaneDev));
     memcpy(blob.data() + off_mats, mats.data(), mats.size() * sizeof(rt_material));
     if (!emit.empty()) memcpy(blob.data() + off_emit, emit.data(), emit.size() * sizeof(RtEmitterDev));
+    if (!grp.pairs.empty()) memcpy(blob.data() + off_gpairs, grp.pairs.data(), grp.pairs.size() * sizeof(float4));
+    if (!grp.ids.empty()) memcpy(blob.data() + off_gids, grp.ids.data(), grp.ids.size() * sizeof(int32_t));
+    if (!grp.heads.empty()) memcpy(blob.data() + off_heads, grp.heads.data(), grp.heads.size() * sizeof(float4));
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // a render may still read the old scene
@@ -295,6 +465,15 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_planes = (int32_t)planes.size();
     ctx->scene.n_objects = n;
     ctx->scene.n_emit = (int32_t)emit.size();
+    ctx->scene.n_pairs = (int32_t)(pairs.size() / 2);
+    ctx->scene.heads = nullptr;
+    ctx->scene.n_groups = 0;
+    ctx->scene_grouped = ctx->scene;
+    ctx->scene_grouped.pairs = (const float4 *)(base + off_gpairs);
+    ctx->scene_grouped.sph_id = (const int32_t *)(base + off_gids);
+    ctx->scene_grouped.heads = (const float4 *)(base + off_heads);
+    ctx->scene_grouped.n_pairs = (int32_t)(grp.pairs.size() / 2);
+    ctx->scene_grouped.n_groups = grp.n_groups;
     ctx->cam = *cam;
     ctx->have_scene = true;
     return RT_OK;
@@ -349,6 +528,8 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad row range [%d,%d) for height %d", y0, y1, p->height);
     if (p->mode != RT_MODE_EXACT && p->mode != RT_MODE_FAST)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", p->mode);
+    if (p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown sweep %d", p->sweep);
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
     if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown output flags 0x%x", outputs);
@@ -375,7 +556,18 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     fr.max_depth = p->max_depth;
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
-    if (ctx->simple_kernel) {
+    bool grouped = false;
+    if (p->sweep == RT_SWEEP_GROUPED && !ctx->simple_kernel && ctx->scene_grouped.n_groups > 0) {
+        // pairs | queue | group heads must fit the LDS budget; larger scenes take the flat sweep
+        const RtSceneDev &g = ctx->scene_grouped;
+        const long avail = (long)ctx->lds_budget - RT_QUEUE_BYTES - 32L * ((g.n_groups + 1) / 2);
+        if (avail >= 32L * g.n_pairs) {
+            grouped = true;
+            fr.chunk = g.n_pairs;
+        }
+    }
+    if (grouped) {
+    } else if (ctx->simple_kernel) {
         int cap = ctx->lds_budget / (int)sizeof(float4);
         fr.chunk = ctx->scene.n_spheres < cap ? ctx->scene.n_spheres : cap;
     } else {
@@ -408,7 +600,8 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         // RT_MODE_FAST: same sweeps, shading by throughput accumulation (no per-segment records).
         // The straight-transcription kernel has only the exact formulation.
         if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
-        else RT_HIP(ctx, rt_launch_trace_sweep(ctx->scene, ctx->cam, fr, smp, sdev, p->mode == RT_MODE_FAST, ctx->stream));
+        else RT_HIP(ctx, rt_launch_trace_sweep(grouped ? ctx->scene_grouped : ctx->scene, ctx->cam, fr, smp, sdev,
+                                               p->mode == RT_MODE_FAST, grouped, ctx->stream));
     }
     RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     ctx->ev_pending.emplace_back(ev0, ev1);
@@ -558,6 +751,8 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
         uint64_t rays = ctx->stats.primary_rays + h.reflection + h.shadow;
         ctx->stats.sphere_tests = rays * (uint64_t)ctx->scene.n_spheres;
         ctx->stats.plane_tests = rays * (uint64_t)ctx->scene.n_planes;
+        ctx->stats.sphere_tests_run = h.sphere_tests_run;
+        ctx->stats.group_tests_run = h.group_tests_run;
         ctx->stats_pending = false;
     }
     *out = ctx->stats;

@@ -11,6 +11,14 @@
 //   planes RtPlaneDev[n_planes]
 //   mats   rt_material[2*n]    [2*k] = object k's material (plane: white), [2*k+1] = plane black
 //   emit   RtEmitterDev[n_emit] objects with a non-zero emissive material, in list order
+//
+// Grouped layout (RT_SWEEP_GROUPED): a second copy of pairs/sph_id in which the spheres are sorted
+// along a Morton curve and cut into GROUPS of at most 16 (8 pair records each, short groups padded
+// with unhittable spheres), plus
+//   heads  float4[2*ceil(n_groups/2)]  bounding spheres of the groups, two per 32-byte record:
+//                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail has R = -1: never passes)
+// A ray whose LINE misses a group's bounding sphere skips the group's 16 spheres.  Slot order is
+// no longer list order there, so distance ties are broken by sph_id explicitly.
 #ifndef RT_DEVICE_H
 #define RT_DEVICE_H
 
@@ -23,6 +31,8 @@
 #define RT_MAX_SPP 64
 #define RT_MAX_PLANES 16
 #define RT_MAX_EMITTERS 64
+#define RT_GROUP_PAIRS 8      // pair records per group (16 spheres)
+#define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
     float ox, oy, oz;
@@ -47,6 +57,9 @@ struct RtSceneDev {
     const rt_material *mats;
     const RtEmitterDev *emit;
     int32_t n_spheres, n_planes, n_objects, n_emit;
+    int32_t n_pairs;      // pair records in `pairs`: ceil(n_spheres/2) flat, 8*n_groups grouped
+    const float4 *heads;  // grouped layout only
+    int32_t n_groups;
 };
 
 struct RtFrameDev {
@@ -61,6 +74,7 @@ struct RtFrameDev {
 
 struct RtStatsDev {
     unsigned long long primary, reflection, shadow, hits, lit;
+    unsigned long long sphere_tests_run, group_tests_run;   // (ray, sphere) filters / (ray, group) tests executed
 };
 
 struct RtSamples {
@@ -69,7 +83,8 @@ struct RtSamples {
 
 // kernel launchers
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
-                                 const RtSamples &samples, RtStatsDev *stats, bool fast, hipStream_t stream);
+                                 const RtSamples &samples, RtStatsDev *stats, bool fast, bool grouped,
+                                 hipStream_t stream);
 hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
 

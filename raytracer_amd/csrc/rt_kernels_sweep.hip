@@ -97,6 +97,7 @@ struct RaySet {
     float best[K];
     int slot[K];    // >= 0 sphere slot, INT_MIN none, < 0 plane: -1 - plane slot
     int id[K];      // list index of the hit (filled by merge_planes)
+    unsigned pairs_run, heads_run;   // pair records / head records this lane put its rays through (stats)
 };
 
 // LDS image: [0, 2*cap) geometry pairs, [2*cap, 4*cap) camera-relative pairs (primary rays).
@@ -140,30 +141,111 @@ __device__ __forceinline__ void build_cam_table(float4 *lds, int cap, int count,
 constexpr int kQueueFields = 7;                          // request: pos, refl, -; result: lit, alt, dist, slot, id
 constexpr int kQueueFloat4 = kQueueFields * kBlock / 4;  // LDS the queue needs, in float4
 
-template <int K>
-__device__ __forceinline__ void exact_pair(RaySet<K> &r, const f2 (&q)[K], float bound, float4 A, float4 B, int slot0,
-                                           int n_spheres)
+// FindNearestObject keeps the first object of the list among equally near ones (strict '>',
+// main.cpp:72).  Flat layout: slots are visited in list order, so strict '>' here does the same.
+// Grouped layout: slot order is not list order, so an exact tie goes to the lower list index.
+template <bool GROUPED>
+__device__ __forceinline__ bool nearer(const RtSceneDev &sc, float best, int best_slot, float dist, int slot)
+{
+    if (best > dist) return true;
+    if (GROUPED && best == dist && best_slot >= 0) return sc.sph_id[slot] < sc.sph_id[best_slot];
+    return false;
+}
+
+template <int K, bool GROUPED>
+__device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, const f2 (&q)[K], float bound, float4 A,
+                                           float4 B, int slot0)
 {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (!r.act[k]) continue;
         float dist;
-        if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) && r.best[k] > dist) {
+        if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) &&
+            nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0)) {
             r.best[k] = dist;
             r.slot[k] = slot0;
         }
-        if (q[k].y <= bound && slot0 + 1 < n_spheres &&
-            sphere_hit(A.y, A.w, B.y, -B.w, r.o[k], r.dn[k], dist) && r.best[k] > dist) {
+        // (padding spheres have -r*r = +FLT_MAX: q is never <= bound for them)
+        if (q[k].y <= bound && (GROUPED || slot0 + 1 < sc.n_spheres) &&
+            sphere_hit(A.y, A.w, B.y, -B.w, r.o[k], r.dn[k], dist) &&
+            nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0 + 1)) {
             r.best[k] = dist;
             r.slot[k] = slot0 + 1;
         }
     }
 }
 
+// The filter + exact test of K rays against one pair record.
+template <int K, bool GROUPED>
+__device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, const float4 A, const float4 B, int slot0,
+                                          const f2 px, const f2 py, const f2 pz, const f2 (&dx)[K], const f2 (&dy)[K],
+                                          const f2 (&dz)[K], float bound)
+{
+    const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
+    const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
+    const f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
+    f2 q[K];
+    // the K chains are independent: issue them stage by stage
+#pragma unroll
+    for (int k = 0; k < K; k++) q[k] = ux * dx[k];
+#pragma unroll
+    for (int k = 0; k < K; k++) q[k] = pk_fma(uy, dy[k], q[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) q[k] = pk_fma(uz, dz[k], q[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) q[k] = pk_fma(-q[k], q[k], w);
+    float m = fminf(q[0].x, q[0].y);
+#pragma unroll
+    for (int k = 1; k < K; k++) m = fminf(fminf(m, q[k].x), q[k].y);
+    if (m <= bound) exact_pair<K, GROUPED>(sc, r, q, bound, A, B, slot0);
+}
+
+// Grouped sweep, phase 1: which of the groups [2*h0, 2*h0 + 2*hn) can any ray of this WAVE touch?
+// A group is skipped when every ray's line passes its bounding sphere (centre g, radius R) at more
+// than R + e, with e^2 = bound + 2^-14 (|g - pos|^2 + R^2).  Soundness: a sphere the reference
+// accepts has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r); the line
+// through o = pos + d*0.001 is the line through pos up to the rounding of o (covered by `bound`);
+// and dist(line, g) <= dist(line, c) + |c - g|, so the group passes with room to spare: e^2 is 64x
+// the rounding it has to cover, which also absorbs the float evaluation of this test itself.
+template <int K>
+__device__ __forceinline__ unsigned long long group_mask(const float4 *heads, int h0, int hn, int n_groups, bool lane_on,
+                                                         const f2 px, const f2 py, const f2 pz, const f2 (&dx)[K],
+                                                         const f2 (&dy)[K], const f2 (&dz)[K], float bound)
+{
+    unsigned long long mask = 0;
+    for (int h = 0; h < hn; h++) {
+        const float4 A = heads[2 * (h0 + h)], B = heads[2 * (h0 + h) + 1];
+        const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
+        const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
+        const f2 R = f2{B.z, B.w};
+        const f2 e2 = pk_fma(pk_fma(R, R, uu), splat(0x1p-14f), splat(bound));
+        const f2 Re = R + f2{__builtin_amdgcn_sqrtf(e2.x), __builtin_amdgcn_sqrtf(e2.y)};
+        const f2 w = pk_fma(-Re, Re, uu);
+        f2 q[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) q[k] = ux * dx[k];
+#pragma unroll
+        for (int k = 0; k < K; k++) q[k] = pk_fma(uy, dy[k], q[k]);
+#pragma unroll
+        for (int k = 0; k < K; k++) q[k] = pk_fma(uz, dz[k], q[k]);
+#pragma unroll
+        for (int k = 0; k < K; k++) q[k] = pk_fma(-q[k], q[k], w);
+        float m0 = q[0].x, m1 = q[0].y;
+#pragma unroll
+        for (int k = 1; k < K; k++) { m0 = fminf(m0, q[k].x); m1 = fminf(m1, q[k].y); }
+        // !(m > 0): a NaN (overflowing radius, non-finite point) keeps the group
+        const bool p0 = lane_on && !(m0 > 0.0f), p1 = lane_on && !(m1 > 0.0f) && 2 * (h0 + h) + 1 < n_groups;
+        if (__ballot(p0)) mask |= 1ull << (2 * h);
+        if (__ballot(p1)) mask |= 2ull << (2 * h);
+    }
+    return mask;
+}
+
 // K rays leaving `pos` against every sphere.  FindNearestObject's order (main.cpp:65-82): spheres
 // are visited in list order with a strict '>' so the lowest index wins ties.
-template <int K, bool CHUNKED>
-__device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap, bool lane_on, V3 pos, RaySet<K> &r)
+template <int K, bool CHUNKED, bool GROUPED>
+__device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool lane_on, V3 pos,
+                                      RaySet<K> &r)
 {
     f2 dx[K], dy[K], dz[K];
 #pragma unroll
@@ -175,33 +257,35 @@ __device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap
     }
     const float bound = filter_bound(pos);
     const f2 px = splat(pos.x), py = splat(pos.y), pz = splat(pos.z);
-    const int n_pairs = (sc.n_spheres + 1) >> 1;
-    for (int base = 0; base < n_pairs; base += cap) {
-        const int count = min(cap, n_pairs - base);
-        if (CHUNKED) stage<true>(sc, lds, cap, base, count, false, pos);
-        if (lane_on) {
-            // (Measured: prefetching the next pair by hand costs 15 %; four waves per SIMD already
-            // cover the LDS latency.)
+    r.pairs_run = r.heads_run = 0;
+    if constexpr (GROUPED && !CHUNKED) {
+        const int n_heads = (sc.n_groups + 1) >> 1;
+        for (int h0 = 0; h0 < n_heads; h0 += 32) {
+            unsigned long long mask = group_mask<K>(heads, h0, min(32, n_heads - h0), sc.n_groups, lane_on, px, py, pz,
+                                                    dx, dy, dz, bound);
+            r.heads_run += min(32, n_heads - h0);
+            while (mask) {                                   // wave-uniform
+                const int g = 2 * h0 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                r.pairs_run += RT_GROUP_PAIRS;
+                if (lane_on) {
 #pragma unroll 2
-            for (int p = 0; p < count; p++) {
-                const float4 A = lds[2 * p], B = lds[2 * p + 1];
-                const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
-                const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
-                const f2 w = pk_fma(uu, splat(kRelKeep), f2{B.z, B.w});
-                f2 q[K];
-                // the K chains are independent: issue them stage by stage
-#pragma unroll
-                for (int k = 0; k < K; k++) q[k] = ux * dx[k];
-#pragma unroll
-                for (int k = 0; k < K; k++) q[k] = pk_fma(uy, dy[k], q[k]);
-#pragma unroll
-                for (int k = 0; k < K; k++) q[k] = pk_fma(uz, dz[k], q[k]);
-#pragma unroll
-                for (int k = 0; k < K; k++) q[k] = pk_fma(-q[k], q[k], w);
-                float m = fminf(q[0].x, q[0].y);
-#pragma unroll
-                for (int k = 1; k < K; k++) m = fminf(fminf(m, q[k].x), q[k].y);
-                if (m <= bound) exact_pair<K>(r, q, bound, A, B, 2 * (base + p), sc.n_spheres);
+                    for (int p = g * RT_GROUP_PAIRS; p < (g + 1) * RT_GROUP_PAIRS; p++)
+                        test_pair<K, true>(sc, r, lds[2 * p], lds[2 * p + 1], 2 * p, px, py, pz, dx, dy, dz, bound);
+                }
+            }
+        }
+    } else {
+        for (int base = 0; base < sc.n_pairs; base += cap) {
+            const int count = min(cap, sc.n_pairs - base);
+            if (CHUNKED) stage<true>(sc, lds, cap, base, count, false, pos);
+            r.pairs_run += count;
+            if (lane_on) {
+                // (Measured: prefetching the next pair by hand costs 15 %; four waves per SIMD already
+                // cover the LDS latency.)
+#pragma unroll 2
+                for (int p = 0; p < count; p++)
+                    test_pair<K, false>(sc, r, lds[2 * p], lds[2 * p + 1], 2 * (base + p), px, py, pz, dx, dy, dz, bound);
             }
         }
     }
@@ -214,9 +298,11 @@ __device__ __forceinline__ void sweep_primary(const RtSceneDev &sc, float4 *lds,
 {
     r.best[0] = FLT_MAX;
     r.slot[0] = INT_MIN;
+    r.pairs_run = (unsigned)sc.n_pairs;
+    r.heads_run = 0;
     const f2 dx = splat(r.dn[0].x), dy = splat(r.dn[0].y), dz = splat(r.dn[0].z);
     const float bound = filter_bound(cam);
-    const int n_pairs = (sc.n_spheres + 1) >> 1;
+    const int n_pairs = sc.n_pairs;
     for (int base = 0; base < n_pairs; base += cap) {
         const int count = min(cap, n_pairs - base);
         if (CHUNKED) stage<true>(sc, lds, cap, base, count, true, cam);
@@ -228,7 +314,7 @@ __device__ __forceinline__ void sweep_primary(const RtSceneDev &sc, float4 *lds,
                 f2 q[1];
                 q[0] = pk_fma(-s, s, f2{W.z, W.w});
                 if (fminf(q[0].x, q[0].y) <= bound)
-                    exact_pair<1>(r, q, bound, lds[2 * p], lds[2 * p + 1], 2 * (base + p), sc.n_spheres);
+                    exact_pair<1, false>(sc, r, q, bound, lds[2 * p], lds[2 * p + 1], 2 * (base + p));
             }
         }
     }
@@ -265,6 +351,10 @@ __device__ __forceinline__ bool block_any(bool v)
     return __any(v) != 0;
 }
 
+struct SweepCount {       // stats: (ray, sphere) and (ray, group) tests this lane executed
+    unsigned tests, gtests;
+};
+
 struct Segment {          // what the next level needs from the sweep that found it
     V3 o, d;              // the ray that produced the hit
     float dist;
@@ -272,10 +362,10 @@ struct Segment {          // what the next level needs from the sweep that found
 };
 
 // Sweeps `ne` shadow rays (emitters e0 .. e0+ne-1) and, when WITH_REFL, the reflection ray in slot 0.
-template <int K, bool WITH_REFL, bool CHUNKED>
-__device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos, V3 refl,
+template <int K, bool WITH_REFL, bool CHUNKED, bool GROUPED>
+__device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool on, V3 pos, V3 refl,
                                             bool want_refl, int e0, unsigned long long &lit,
-                                            unsigned long long &alt, Segment &next, bool &next_hit)
+                                            unsigned long long &alt, Segment &next, bool &next_hit, SweepCount &cnt)
 {
     RaySet<K> r;
     constexpr int kFirst = WITH_REFL ? 1 : 0;
@@ -294,9 +384,12 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, i
         r.dn[k] = normalize(edir);
         r.act[k] = on;
     }
-    sweep<K, CHUNKED>(sc, lds, cap, on, pos, r);
+    sweep<K, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, r);
     merge_planes<K>(sc, on, r);
     if (on) {
+        const unsigned n_act = (unsigned)(K - kFirst) + ((WITH_REFL && want_refl) ? 1u : 0u);
+        cnt.tests += 2u * n_act * r.pairs_run;
+        cnt.gtests += 2u * n_act * r.heads_run;
 #pragma unroll
         for (int k = kFirst; k < K; k++) {
             // lit iff the nearest object along the shadow ray (lowest index on ties) is the emitter
@@ -323,17 +416,17 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, i
     }
 }
 
-template <bool WITH_REFL, bool CHUNKED>
-__device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos,
+template <bool WITH_REFL, bool CHUNKED, bool GROUPED>
+__device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool on, V3 pos,
                                               V3 refl, bool want_refl, int e0, unsigned long long &lit,
-                                              unsigned long long &alt, Segment &next, bool &next_hit)
+                                              unsigned long long &alt, Segment &next, bool &next_hit, SweepCount &cnt)
 {
     switch (k_total) {       // uniform across the workgroup
-    case 1: trace_group<1, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
-    case 2: trace_group<2, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
-    case 3: trace_group<3, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
-    case 4: trace_group<4, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
-    default: trace_group<5, WITH_REFL, CHUNKED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit); break;
+    case 1: trace_group<1, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 2: trace_group<2, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 3: trace_group<3, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 4: trace_group<4, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    default: trace_group<5, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
     }
 }
 
@@ -385,7 +478,7 @@ __device__ __forceinline__ V3 add_lights(const RtSceneDev &sc, V3 out, V3 pos, V
 // so a segment is shaded as soon as its shadow mask is known and nothing is kept in private memory.
 // Same hits, same lights; the sum associates differently, so radiance agrees with the reference to
 // rounding (<= 1e-5 relative, tested at 1e-4), not bit for bit.
-template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS, bool FAST>
+template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS, bool FAST, bool GROUPED>
 __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_SMALL) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
@@ -412,7 +505,13 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
     __shared__ int q_count[2];                        // [0] requests with a reflection ray, [1] without
     unsigned *const queue = reinterpret_cast<unsigned *>(lds + 2 * cap);   // aliases the camera table
     if (threadIdx.x == 0) q_count[0] = q_count[1] = 0;
-    if (!CHUNKED) stage<false>(sc, lds, cap, 0, (sc.n_spheres + 1) >> 1, false, cam_pos);
+    if (!CHUNKED) stage<false>(sc, lds, cap, 0, sc.n_pairs, false, cam_pos);
+    // grouped layout: the group heads sit behind the queue (there is no camera table)
+    float4 *const heads = lds + 2 * cap + kQueueFloat4;
+    if constexpr (GROUPED) {
+        for (int h = threadIdx.x; h < 2 * ((sc.n_groups + 1) >> 1); h += kBlock) heads[h] = sc.heads[h];
+        __syncthreads();
+    }
 
     // one record per path segment, read back deepest-first (runtime-indexed -> private memory)
     // LEVELS >= max_depth + 1 (the launcher picks the smallest instantiation that fits: the
@@ -424,6 +523,7 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
     unsigned long long rec_lit[kRec], rec_alt[kRec];
 
     unsigned n_refl = 0, n_shadow = 0, n_hits = 0, n_lit = 0;
+    SweepCount cnt = {0u, 0u};
     V3 color = v3(0.0f, 0.0f, 0.0f);
 
     for (int s = 0; s < fr.spp; s++) {                                       // main.cpp:203
@@ -442,9 +542,14 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
             r.d[0] = normalize(d);
             r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
             r.act[0] = in_image;
-            if (!CHUNKED) build_cam_table(lds, cap, (sc.n_spheres + 1) >> 1, cam_pos);
-            sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
+            if constexpr (GROUPED) {
+                sweep<1, CHUNKED, true>(sc, lds, heads, cap, in_image, cam_pos, r);
+            } else {
+                if (!CHUNKED) build_cam_table(lds, cap, sc.n_pairs, cam_pos);
+                sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
+            }
             merge_planes<1>(sc, in_image, r);
+            if (in_image) { cnt.tests += 2u * r.pairs_run; cnt.gtests += 2u * r.heads_run; }
             seg.o = r.o[0]; seg.d = r.d[0]; seg.dist = r.best[0]; seg.slot = r.slot[0]; seg.id = r.id[0];
             alive = in_image && r.slot[0] != INT_MIN;
         }
@@ -538,12 +643,12 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
                 int e0 = 0;
                 if (any_refl) {
                     const int ne = min(sc.n_emit, kMaxK - 1);
-                    trace_group_k<true, CHUNKED>(1 + ne, sc, lds, cap, w_on, w_pos, w_dir, w_refl, 0, lit, alt, next, next_hit);
+                    trace_group_k<true, CHUNKED, GROUPED>(1 + ne, sc, lds, heads, cap, w_on, w_pos, w_dir, w_refl, 0, lit, alt, next, next_hit, cnt);
                     e0 = ne;
                 }
                 while (e0 < sc.n_emit) {
                     const int ne = min(sc.n_emit - e0, kMaxK);
-                    trace_group_k<false, CHUNKED>(ne, sc, lds, cap, w_on, w_pos, w_dir, false, e0, lit, alt, next, next_hit);
+                    trace_group_k<false, CHUNKED, GROUPED>(ne, sc, lds, heads, cap, w_on, w_pos, w_dir, false, e0, lit, alt, next, next_hit, cnt);
                     e0 += ne;
                 }
                 if (COMPACT && w_on) {
@@ -634,47 +739,64 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
             for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
             if (lane == 0 && t) atomicAdd(dst[k], (unsigned long long)t);
         }
+        // executed tests are counted by the lane that swept (under compaction not the pixel's own)
+        unsigned long long w[2] = {cnt.tests, cnt.gtests};
+        unsigned long long *wdst[2] = {&stats->sphere_tests_run, &stats->group_tests_run};
+        for (int k = 0; k < 2; k++) {
+            unsigned long long t = w[k];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0 && t) atomicAdd(wdst[k], t);
+        }
     }
 }
 
 } // namespace
 
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
-                                 const RtSamples &samples, RtStatsDev *stats, bool fast, hipStream_t stream)
+                                 const RtSamples &samples, RtStatsDev *stats, bool fast, bool grouped,
+                                 hipStream_t stream)
 {
     const int rows = frame.row_end - frame.row_begin;
     const int tiles = ((frame.width + 7) / 8) * ((rows + 7) / 8);
     if (tiles <= 0) return hipSuccess;
     const dim3 grid((tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    const int n_pairs = (scene.n_spheres + 1) / 2;
+    const int n_pairs = scene.n_pairs;
     const bool chunked = frame.chunk < n_pairs;
     const int cap = frame.chunk > 0 ? frame.chunk : 1;
-    const size_t lds_bytes = (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
+    // flat: pairs | camera table or queue;  grouped: pairs | queue | group heads
+    const size_t lds_bytes = grouped ? (size_t)(2 * cap + kQueueFloat4 + 2 * ((scene.n_groups + 1) / 2)) * sizeof(float4)
+                                     : (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
+    if (grouped && chunked) return hipErrorInvalidValue;     // the caller sizes grouped scenes to fit
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     const bool compact = n_pairs >= 24;
-#define RT_LAUNCH_L(C, P, S, L, F)                                                                                       \
+#define RT_LAUNCH_G(C, P, S, L, F, G)                                                                                   \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \
-            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S, L, F>,                           \
+            hipError_t e_ = hipFuncSetAttribute((const void *)trace_sweep_kernel<C, P, S, L, F, G>,                     \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e_ != hipSuccess) return e_;                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S, L, F>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
+        hipLaunchKernelGGL((trace_sweep_kernel<C, P, S, L, F, G>), grid, block, lds_bytes, stream, scene, cam, frame, samples, stats); \
     } while (0)
-#define RT_LAUNCH(C, P, S)                                      \
-    do {                                                        \
-        if (fast) RT_LAUNCH_L(C, P, S, 1, true);                       \
-        else if (frame.max_depth < 6) RT_LAUNCH_L(C, P, S, 6, false);  \
-        else RT_LAUNCH_L(C, P, S, RT_MAX_LEVELS, false);               \
+#define RT_LAUNCH(C, P, S, G)                                             \
+    do {                                                                  \
+        if (fast) RT_LAUNCH_G(C, P, S, 1, true, G);                       \
+        else if (frame.max_depth < 6) RT_LAUNCH_G(C, P, S, 6, false, G);  \
+        else RT_LAUNCH_G(C, P, S, RT_MAX_LEVELS, false, G);               \
+    } while (0)
+#define RT_LAUNCH_S(C, P, G)                                              \
+    do {                                                                  \
+        if (stats) RT_LAUNCH(C, P, true, G); else RT_LAUNCH(C, P, false, G); \
     } while (0)
     if (chunked) {
-        if (stats) RT_LAUNCH(true, true, true); else RT_LAUNCH(true, true, false);
-    } else if (compact) {
-        if (stats) RT_LAUNCH(false, true, true); else RT_LAUNCH(false, true, false);
+        RT_LAUNCH_S(true, true, false);
+    } else if (grouped) {
+        if (compact) RT_LAUNCH_S(false, true, true); else RT_LAUNCH_S(false, false, true);
     } else {
-        if (stats) RT_LAUNCH(false, false, true); else RT_LAUNCH(false, false, false);
+        if (compact) RT_LAUNCH_S(false, true, false); else RT_LAUNCH_S(false, false, false);
     }
+#undef RT_LAUNCH_S
 #undef RT_LAUNCH
-#undef RT_LAUNCH_L
+#undef RT_LAUNCH_G
     return hipGetLastError();
 }
