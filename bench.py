@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--sweep", default="flat", choices=["flat", "grouped"],
-                    help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 16 are skipped when missed")
+    ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped"],
+                    help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 16 are skipped when "
+                         "missed; auto (the library default): grouped from 64 spheres up")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
@@ -91,7 +92,7 @@ def main():
 
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
     mode = capi.RT_MODE_EXACT if args.mode == "exact" else capi.RT_MODE_FAST
-    sweep = capi.RT_SWEEP_GROUPED if args.sweep == "grouped" else capi.RT_SWEEP_FLAT
+    sweep = {"auto": capi.RT_SWEEP_AUTO, "flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED}[args.sweep]
     W, H = args.width, args.height
     objs, cam = capi.make_scene(kind, W, H)
     ctx = capi.Context(local)
@@ -187,7 +188,7 @@ def main():
                                    f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}, sweep {args.sweep}",
                        "rays_per_frame": int(rays), "bands": bounds,
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
-                                                                         "sphere_tests", "sphere_tests_run", "group_tests_run")},
+                                                                         "sphere_tests", "sphere_tests_run", "group_tests_run", "exact_tests_run")},
                        "parallelism": f"row-bands x{world}" + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,

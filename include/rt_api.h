@@ -105,12 +105,15 @@ enum {
     RT_MODE_FAST = 1    /* FMA contraction + throughput accumulator; radiance within 1e-4 rel    */
 };
 
-/* How a ray visits the sphere list.  Both give the same image, bit for bit. */
+/* How a ray visits the sphere list.  Every choice gives the same image, bit for bit. */
 enum {
-    RT_SWEEP_FLAT = 0,   /* every ray is tested against every sphere, list streamed through LDS:
+    RT_SWEEP_AUTO = 0,   /* grouped for scenes of 64 spheres or more, flat below                    */
+    RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */
-    RT_SWEEP_GROUPED = 1 /* spheres are grouped (16 per group, Morton order) at upload; a ray whose
-                            line misses a group's bounding sphere skips the group                  */
+    RT_SWEEP_GROUPED = 2 /* spheres are grouped at upload (16 per group along a Morton curve, 16
+                            groups per super-group); a wave skips a group when the lines of all its
+                            rays miss the group's bounding sphere.  Scenes of fewer than 64 spheres
+                            take the flat sweep regardless                                         */
 };
 
 typedef struct rt_render_params {
@@ -144,6 +147,8 @@ typedef struct rt_stats {
     uint64_t sphere_tests_run;  /* (ray, sphere) tests the kernel executed: = sphere_tests (+ odd-tail
                                    padding) for RT_SWEEP_FLAT, fewer for RT_SWEEP_GROUPED            */
     uint64_t group_tests_run;   /* (ray, group) bounding-sphere tests executed (RT_SWEEP_GROUPED)   */
+    uint64_t exact_tests_run;   /* (ray, sphere) candidates of the filter that took the reference's
+                                   exact test (the accept path of glm::intersectRaySphere and more)  */
 } rt_stats;
 
 typedef struct rt_context rt_context;

@@ -19,7 +19,7 @@ RT_OBJ_SPHERE, RT_OBJ_TILED_PLANE = 0, 1
 RT_OUT_RGBA8, RT_OUT_F32X4 = 1, 2
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
-RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1
+RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2
 RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
 
 
@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                  "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + \
                [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("kernels_timed", C.c_uint64),
-                ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64)]
+                ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64), ("exact_tests_run", C.c_uint64)]
 
 
 EXPORTS = [

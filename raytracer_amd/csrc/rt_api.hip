@@ -4,6 +4,7 @@
 #include "rt_device.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -219,7 +220,8 @@ struct GroupedScene {
     std::vector<int32_t> ids;      // 2 * RT_GROUP_PAIRS * n_groups (list index, -1 = padding)
     std::vector<int32_t> slot_of;  // geom index -> slot
     std::vector<float4> heads;     // 2 * ceil(n_groups / 2)
-    int n_groups = 0;
+    std::vector<float4> supers;    // 2 * ceil(n_supers / 2)
+    int n_groups = 0, n_supers = 0;
 };
 
 static uint32_t spread10(uint32_t v)
@@ -347,22 +349,52 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
             out.slot_of[m[j]] = (int32_t)slot;
         }
     }
-    out.heads.assign(2 * ((groups.size() + 1) / 2), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    for (size_t g = 0; g < out.heads.size(); g++) {
-        float c[3] = {0.0f, 0.0f, 0.0f}, R = -1.0f;          // odd tail: R < 0 marks "no group"
-        if (g < groups.size()) {
-            for (int a = 0; a < 3; a++) c[a] = (float)groups[g].c[a];
-            // the centre was rounded to float: widen by that displacement, then round the radius up
+    // bounding spheres, two per record; the centre is rounded to float, so the radius is widened by
+    // that displacement and then rounded up
+    auto pack_heads = [](const std::vector<std::array<double, 4>> &b, std::vector<float4> &dst) {
+        dst.assign(2 * ((b.size() + 1) / 2), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        for (size_t g = 0; g < b.size(); g++) {
+            float c[3];
             double d2 = 0;
-            for (int a = 0; a < 3; a++) d2 += ((double)c[a] - groups[g].c[a]) * ((double)c[a] - groups[g].c[a]);
-            const double Rd = (groups[g].R + std::sqrt(d2)) * (1.0 + 0x1p-20);
-            R = std::isfinite(Rd) && Rd < 1e37 ? std::nextafterf((float)Rd, INFINITY) : INFINITY;
-            if (!(Rd == Rd)) R = INFINITY;                    // NaN bound: always visit
+            for (int a = 0; a < 3; a++) {
+                c[a] = (float)b[g][a];
+                d2 += ((double)c[a] - b[g][a]) * ((double)c[a] - b[g][a]);
+            }
+            const double Rd = (b[g][3] + std::sqrt(d2)) * (1.0 + 0x1p-20);
+            // a NaN or overflowing bound: always visit
+            const float R = (Rd == Rd) && Rd < 1e37 ? std::nextafterf((float)Rd, INFINITY) : INFINITY;
+            float4 &A = dst[2 * (g >> 1)], &B = dst[2 * (g >> 1) + 1];
+            if (g & 1) { A.y = c[0]; A.w = c[1]; B.y = c[2]; B.w = R; }
+            else       { A.x = c[0]; A.z = c[1]; B.x = c[2]; B.z = R; }
         }
-        float4 &A = out.heads[2 * (g >> 1)], &B = out.heads[2 * (g >> 1) + 1];
-        if (g & 1) { A.y = c[0]; A.w = c[1]; B.y = c[2]; B.w = R; }
-        else       { A.x = c[0]; A.z = c[1]; B.x = c[2]; B.z = R; }
+    };
+    std::vector<std::array<double, 4>> gb(groups.size());
+    for (size_t g = 0; g < groups.size(); g++) gb[g] = {groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].R};
+    pack_heads(gb, out.heads);
+
+    // super-groups: RT_SUPER_GROUPS consecutive groups (Morton neighbours), bounded the same way
+    out.n_supers = (int)((groups.size() + RT_SUPER_GROUPS - 1) / RT_SUPER_GROUPS);
+    std::vector<std::array<double, 4>> sb(out.n_supers);
+    for (int sgi = 0; sgi < out.n_supers; sgi++) {
+        const size_t g0 = (size_t)sgi * RT_SUPER_GROUPS, g1 = std::min(groups.size(), g0 + RT_SUPER_GROUPS);
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        bool ok = true;
+        for (size_t g = g0; g < g1; g++) {
+            ok = ok && std::isfinite(groups[g].R) && std::isfinite(groups[g].c[0] + groups[g].c[1] + groups[g].c[2]);
+            for (int a = 0; a < 3; a++) {
+                blo[a] = std::min(blo[a], groups[g].c[a] - groups[g].R);
+                bhi[a] = std::max(bhi[a], groups[g].c[a] + groups[g].R);
+            }
+        }
+        double c[3], R = 0;
+        for (int a = 0; a < 3; a++) c[a] = ok ? 0.5 * (blo[a] + bhi[a]) : 0.0;
+        for (size_t g = g0; g < g1 && ok; g++) {
+            const double dx = groups[g].c[0] - c[0], dy = groups[g].c[1] - c[1], dz = groups[g].c[2] - c[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + groups[g].R);
+        }
+        sb[sgi] = {c[0], c[1], c[2], ok ? R : INFINITY};
     }
+    pack_heads(sb, out.supers);
 }
 
 int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_camera *cam)
@@ -429,7 +461,8 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     size_t off_gpairs = align(off_emit + emit.size() * sizeof(RtEmitterDev));
     size_t off_gids = align(off_gpairs + grp.pairs.size() * sizeof(float4));
     size_t off_heads = align(off_gids + grp.ids.size() * sizeof(int32_t));
-    size_t total = align(off_heads + grp.heads.size() * sizeof(float4)) + 256;
+    size_t off_supers = align(off_heads + grp.heads.size() * sizeof(float4));
+    size_t total = align(off_supers + grp.supers.size() * sizeof(float4)) + 256;
 
     std::vector<uint8_t> blob(total, 0);
     if (!pairs.empty()) memcpy(blob.data() + off_pairs, pairs.data(), pairs.size() * sizeof(float4));
@@ -441,6 +474,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (!grp.pairs.empty()) memcpy(blob.data() + off_gpairs, grp.pairs.data(), grp.pairs.size() * sizeof(float4));
     if (!grp.ids.empty()) memcpy(blob.data() + off_gids, grp.ids.data(), grp.ids.size() * sizeof(int32_t));
     if (!grp.heads.empty()) memcpy(blob.data() + off_heads, grp.heads.data(), grp.heads.size() * sizeof(float4));
+    if (!grp.supers.empty()) memcpy(blob.data() + off_supers, grp.supers.data(), grp.supers.size() * sizeof(float4));
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // a render may still read the old scene
@@ -466,14 +500,16 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_objects = n;
     ctx->scene.n_emit = (int32_t)emit.size();
     ctx->scene.n_pairs = (int32_t)(pairs.size() / 2);
-    ctx->scene.heads = nullptr;
-    ctx->scene.n_groups = 0;
+    ctx->scene.heads = ctx->scene.supers = nullptr;
+    ctx->scene.n_groups = ctx->scene.n_supers = 0;
     ctx->scene_grouped = ctx->scene;
     ctx->scene_grouped.pairs = (const float4 *)(base + off_gpairs);
     ctx->scene_grouped.sph_id = (const int32_t *)(base + off_gids);
     ctx->scene_grouped.heads = (const float4 *)(base + off_heads);
     ctx->scene_grouped.n_pairs = (int32_t)(grp.pairs.size() / 2);
+    ctx->scene_grouped.supers = (const float4 *)(base + off_supers);
     ctx->scene_grouped.n_groups = grp.n_groups;
+    ctx->scene_grouped.n_supers = grp.n_supers;
     ctx->cam = *cam;
     ctx->have_scene = true;
     return RT_OK;
@@ -528,7 +564,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad row range [%d,%d) for height %d", y0, y1, p->height);
     if (p->mode != RT_MODE_EXACT && p->mode != RT_MODE_FAST)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", p->mode);
-    if (p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
+    if (p->sweep != RT_SWEEP_AUTO && p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown sweep %d", p->sweep);
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
     if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4))
@@ -557,14 +593,10 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
     bool grouped = false;
-    if (p->sweep == RT_SWEEP_GROUPED && !ctx->simple_kernel && ctx->scene_grouped.n_groups > 0) {
-        // pairs | queue | group heads must fit the LDS budget; larger scenes take the flat sweep
-        const RtSceneDev &g = ctx->scene_grouped;
-        const long avail = (long)ctx->lds_budget - RT_QUEUE_BYTES - 32L * ((g.n_groups + 1) / 2);
-        if (avail >= 32L * g.n_pairs) {
-            grouped = true;
-            fr.chunk = g.n_pairs;
-        }
+    // (scenes of a few dozen spheres gain nothing from grouping: they always take the flat sweep)
+    if (p->sweep != RT_SWEEP_FLAT && !ctx->simple_kernel && ctx->scene.n_spheres >= 64) {
+        grouped = true;
+        fr.chunk = 0;         // nothing is staged in LDS: the grouped arrays are read through the scalar cache
     }
     if (grouped) {
     } else if (ctx->simple_kernel) {
@@ -753,6 +785,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
         ctx->stats.plane_tests = rays * (uint64_t)ctx->scene.n_planes;
         ctx->stats.sphere_tests_run = h.sphere_tests_run;
         ctx->stats.group_tests_run = h.group_tests_run;
+        ctx->stats.exact_tests_run = h.exact_tests_run;
         ctx->stats_pending = false;
     }
     *out = ctx->stats;

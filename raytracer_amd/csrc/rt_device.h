@@ -17,7 +17,10 @@
 // with unhittable spheres), plus
 //   heads  float4[2*ceil(n_groups/2)]  bounding spheres of the groups, two per 32-byte record:
 //                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail has R = -1: never passes)
-// A ray whose LINE misses a group's bounding sphere skips the group's 16 spheres.  Slot order is
+//   supers float4[2*ceil(n_supers/2)]  the same one level up: bounding spheres of RT_SUPER_GROUPS
+//                              consecutive groups
+// A ray whose LINE misses a group's bounding sphere skips the group's 16 spheres.  The grouped
+// arrays are read with wave-uniform scalar loads straight from HBM/L2: no LDS staging, no size limit.  Slot order is
 // no longer list order there, so distance ties are broken by sph_id explicitly.
 #ifndef RT_DEVICE_H
 #define RT_DEVICE_H
@@ -32,6 +35,7 @@
 #define RT_MAX_PLANES 16
 #define RT_MAX_EMITTERS 64
 #define RT_GROUP_PAIRS 8      // pair records per group (16 spheres)
+#define RT_SUPER_GROUPS 16     // groups per super-group (256 spheres)
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
@@ -58,8 +62,9 @@ struct RtSceneDev {
     const RtEmitterDev *emit;
     int32_t n_spheres, n_planes, n_objects, n_emit;
     int32_t n_pairs;      // pair records in `pairs`: ceil(n_spheres/2) flat, 8*n_groups grouped
-    const float4 *heads;  // grouped layout only
-    int32_t n_groups;
+    const float4 *heads;  // grouped layout only: bounding spheres of the groups ...
+    const float4 *supers; // ... and of the super-groups (RT_SUPER_GROUPS consecutive groups each)
+    int32_t n_groups, n_supers;
 };
 
 struct RtFrameDev {
@@ -75,6 +80,7 @@ struct RtFrameDev {
 struct RtStatsDev {
     unsigned long long primary, reflection, shadow, hits, lit;
     unsigned long long sphere_tests_run, group_tests_run;   // (ray, sphere) filters / (ray, group) tests executed
+    unsigned long long exact_tests_run;                     // (ray, sphere) candidates put through the exact test
 };
 
 struct RtSamples {

@@ -56,6 +56,16 @@ constexpr float kRelKeep = 1.0f - 0x1p-17f;    // filter: uu * (1 - 2^-17)
 constexpr float kAbsScale = 0x1p-19f;          // filter: 2^-19 * (|pos|^2 + 2^-13)
 constexpr float kAbsFloor = 0x1p-13f;
 
+// A wave-uniform read of read-only scene data through the scalar cache (s_load_dwordx4): the
+// constant address space is what makes the compiler pick scalar loads.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 uniform_load(const float4 *base, int idx)
+{
+    const __attribute__((address_space(4))) f4v *cp = (const __attribute__((address_space(4))) f4v *)base;
+    const f4v v = cp[idx];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -98,6 +108,7 @@ struct RaySet {
     int slot[K];    // >= 0 sphere slot, INT_MIN none, < 0 plane: -1 - plane slot
     int id[K];      // list index of the hit (filled by merge_planes)
     unsigned pairs_run, heads_run;   // pair records / head records this lane put its rays through (stats)
+    unsigned cand_run;               // (ray, sphere) candidates that went to the exact test
 };
 
 // LDS image: [0, 2*cap) geometry pairs, [2*cap, 4*cap) camera-relative pairs (primary rays).
@@ -160,6 +171,7 @@ __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, c
     for (int k = 0; k < K; k++) {
         if (!r.act[k]) continue;
         float dist;
+        r.cand_run += (q[k].x <= bound ? 1u : 0u) + (q[k].y <= bound ? 1u : 0u);
         if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) &&
             nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0)) {
             r.best[k] = dist;
@@ -200,21 +212,23 @@ __device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, co
     if (m <= bound) exact_pair<K, GROUPED>(sc, r, q, bound, A, B, slot0);
 }
 
-// Grouped sweep, phase 1: which of the groups [2*h0, 2*h0 + 2*hn) can any ray of this WAVE touch?
-// A group is skipped when every ray's line passes its bounding sphere (centre g, radius R) at more
-// than R + e, with e^2 = bound + 2^-14 (|g - pos|^2 + R^2).  Soundness: a sphere the reference
-// accepts has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r); the line
-// through o = pos + d*0.001 is the line through pos up to the rounding of o (covered by `bound`);
-// and dist(line, g) <= dist(line, c) + |c - g|, so the group passes with room to spare: e^2 is 64x
-// the rounding it has to cover, which also absorbs the float evaluation of this test itself.
+// Grouped sweep: which of the bounding spheres [2*h0, 2*h0 + 2*hn) of `heads` can any ray of this
+// WAVE touch?  (Group heads, or the super-group heads one level up: same record, same test.)
+// A bounding sphere (centre g, radius R) is skipped when every ray's line passes it at more than
+// R + e, with e^2 = bound + 2^-14 (|g - pos|^2 + R^2).  Soundness: a sphere the reference accepts
+// has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r); the line through
+// o = pos + d*0.001 is the line through pos up to the rounding of o (covered by `bound`); and
+// dist(line, g) <= dist(line, c) + |c - g| <= dist(line, c) + R - r, so the bound passes with room
+// to spare: e^2 is 64x the rounding it has to cover, which also absorbs the float evaluation of this
+// test itself.  The records are read with wave-uniform scalar loads; no LDS is involved.
 template <int K>
-__device__ __forceinline__ unsigned long long group_mask(const float4 *heads, int h0, int hn, int n_groups, bool lane_on,
+__device__ __forceinline__ unsigned long long group_mask(const float4 *heads, int h0, int hn, int n_total, bool lane_on,
                                                          const f2 px, const f2 py, const f2 pz, const f2 (&dx)[K],
                                                          const f2 (&dy)[K], const f2 (&dz)[K], float bound)
 {
     unsigned long long mask = 0;
     for (int h = 0; h < hn; h++) {
-        const float4 A = heads[2 * (h0 + h)], B = heads[2 * (h0 + h) + 1];
+        const float4 A = uniform_load(heads, 2 * (h0 + h)), B = uniform_load(heads, 2 * (h0 + h) + 1);
         const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
         const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
         const f2 R = f2{B.z, B.w};
@@ -234,7 +248,7 @@ __device__ __forceinline__ unsigned long long group_mask(const float4 *heads, in
 #pragma unroll
         for (int k = 1; k < K; k++) { m0 = fminf(m0, q[k].x); m1 = fminf(m1, q[k].y); }
         // !(m > 0): a NaN (overflowing radius, non-finite point) keeps the group
-        const bool p0 = lane_on && !(m0 > 0.0f), p1 = lane_on && !(m1 > 0.0f) && 2 * (h0 + h) + 1 < n_groups;
+        const bool p0 = lane_on && !(m0 > 0.0f), p1 = lane_on && !(m1 > 0.0f) && 2 * (h0 + h) + 1 < n_total;
         if (__ballot(p0)) mask |= 1ull << (2 * h);
         if (__ballot(p1)) mask |= 2ull << (2 * h);
     }
@@ -244,8 +258,7 @@ __device__ __forceinline__ unsigned long long group_mask(const float4 *heads, in
 // K rays leaving `pos` against every sphere.  FindNearestObject's order (main.cpp:65-82): spheres
 // are visited in list order with a strict '>' so the lowest index wins ties.
 template <int K, bool CHUNKED, bool GROUPED>
-__device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool lane_on, V3 pos,
-                                      RaySet<K> &r)
+__device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, int cap, bool lane_on, V3 pos, RaySet<K> &r)
 {
     f2 dx[K], dy[K], dz[K];
 #pragma unroll
@@ -257,21 +270,32 @@ __device__ __forceinline__ void sweep(const RtSceneDev &sc, float4 *lds, const f
     }
     const float bound = filter_bound(pos);
     const f2 px = splat(pos.x), py = splat(pos.y), pz = splat(pos.z);
-    r.pairs_run = r.heads_run = 0;
-    if constexpr (GROUPED && !CHUNKED) {
-        const int n_heads = (sc.n_groups + 1) >> 1;
-        for (int h0 = 0; h0 < n_heads; h0 += 32) {
-            unsigned long long mask = group_mask<K>(heads, h0, min(32, n_heads - h0), sc.n_groups, lane_on, px, py, pz,
-                                                    dx, dy, dz, bound);
-            r.heads_run += min(32, n_heads - h0);
-            while (mask) {                                   // wave-uniform
-                const int g = 2 * h0 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                r.pairs_run += RT_GROUP_PAIRS;
-                if (lane_on) {
+    r.pairs_run = r.heads_run = r.cand_run = 0;
+    if constexpr (GROUPED) {
+        // two levels: super-groups of RT_SUPER_GROUPS groups, groups of 2*RT_GROUP_PAIRS spheres; the
+        // masks are wave-uniform (SGPRs), so all of this is scalar control flow
+        constexpr int kHeadsPerSuper = RT_SUPER_GROUPS / 2;
+        const int n_super_heads = (sc.n_supers + 1) >> 1, n_heads = (sc.n_groups + 1) >> 1;
+        for (int s0 = 0; s0 < n_super_heads; s0 += 32) {
+            const int sn = min(32, n_super_heads - s0);
+            unsigned long long smask = group_mask<K>(sc.supers, s0, sn, sc.n_supers, lane_on, px, py, pz, dx, dy, dz, bound);
+            r.heads_run += sn;
+            while (smask) {
+                const int sg = 2 * s0 + __builtin_ctzll(smask);
+                smask &= smask - 1;
+                const int h0 = sg * kHeadsPerSuper, hn = min(kHeadsPerSuper, n_heads - h0);
+                unsigned long long mask = group_mask<K>(sc.heads, h0, hn, sc.n_groups, lane_on, px, py, pz, dx, dy, dz, bound);
+                r.heads_run += hn;
+                while (mask) {
+                    const int g = 2 * h0 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    r.pairs_run += RT_GROUP_PAIRS;
+                    if (lane_on) {
 #pragma unroll 2
-                    for (int p = g * RT_GROUP_PAIRS; p < (g + 1) * RT_GROUP_PAIRS; p++)
-                        test_pair<K, true>(sc, r, lds[2 * p], lds[2 * p + 1], 2 * p, px, py, pz, dx, dy, dz, bound);
+                        for (int p = g * RT_GROUP_PAIRS; p < (g + 1) * RT_GROUP_PAIRS; p++)
+                            test_pair<K, true>(sc, r, uniform_load(sc.pairs, 2 * p), uniform_load(sc.pairs, 2 * p + 1), 2 * p,
+                                               px, py, pz, dx, dy, dz, bound);
+                    }
                 }
             }
         }
@@ -299,7 +323,7 @@ __device__ __forceinline__ void sweep_primary(const RtSceneDev &sc, float4 *lds,
     r.best[0] = FLT_MAX;
     r.slot[0] = INT_MIN;
     r.pairs_run = (unsigned)sc.n_pairs;
-    r.heads_run = 0;
+    r.heads_run = r.cand_run = 0;
     const f2 dx = splat(r.dn[0].x), dy = splat(r.dn[0].y), dz = splat(r.dn[0].z);
     const float bound = filter_bound(cam);
     const int n_pairs = sc.n_pairs;
@@ -351,8 +375,8 @@ __device__ __forceinline__ bool block_any(bool v)
     return __any(v) != 0;
 }
 
-struct SweepCount {       // stats: (ray, sphere) and (ray, group) tests this lane executed
-    unsigned tests, gtests;
+struct SweepCount {       // stats: (ray, sphere) filters, (ray, group) tests, exact tests this lane executed
+    unsigned tests, gtests, cands;
 };
 
 struct Segment {          // what the next level needs from the sweep that found it
@@ -363,7 +387,7 @@ struct Segment {          // what the next level needs from the sweep that found
 
 // Sweeps `ne` shadow rays (emitters e0 .. e0+ne-1) and, when WITH_REFL, the reflection ray in slot 0.
 template <int K, bool WITH_REFL, bool CHUNKED, bool GROUPED>
-__device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool on, V3 pos, V3 refl,
+__device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos, V3 refl,
                                             bool want_refl, int e0, unsigned long long &lit,
                                             unsigned long long &alt, Segment &next, bool &next_hit, SweepCount &cnt)
 {
@@ -384,12 +408,13 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, c
         r.dn[k] = normalize(edir);
         r.act[k] = on;
     }
-    sweep<K, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, r);
+    sweep<K, CHUNKED, GROUPED>(sc, lds, cap, on, pos, r);
     merge_planes<K>(sc, on, r);
     if (on) {
         const unsigned n_act = (unsigned)(K - kFirst) + ((WITH_REFL && want_refl) ? 1u : 0u);
         cnt.tests += 2u * n_act * r.pairs_run;
         cnt.gtests += 2u * n_act * r.heads_run;
+        cnt.cands += r.cand_run;
 #pragma unroll
         for (int k = kFirst; k < K; k++) {
             // lit iff the nearest object along the shadow ray (lowest index on ties) is the emitter
@@ -417,16 +442,16 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, c
 }
 
 template <bool WITH_REFL, bool CHUNKED, bool GROUPED>
-__device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc, float4 *lds, const float4 *heads, int cap, bool on, V3 pos,
+__device__ __forceinline__ void trace_group_k(int k_total, const RtSceneDev &sc, float4 *lds, int cap, bool on, V3 pos,
                                               V3 refl, bool want_refl, int e0, unsigned long long &lit,
                                               unsigned long long &alt, Segment &next, bool &next_hit, SweepCount &cnt)
 {
     switch (k_total) {       // uniform across the workgroup
-    case 1: trace_group<1, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
-    case 2: trace_group<2, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
-    case 3: trace_group<3, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
-    case 4: trace_group<4, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
-    default: trace_group<5, WITH_REFL, CHUNKED, GROUPED>(sc, lds, heads, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 1: trace_group<1, WITH_REFL, CHUNKED, GROUPED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 2: trace_group<2, WITH_REFL, CHUNKED, GROUPED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 3: trace_group<3, WITH_REFL, CHUNKED, GROUPED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    case 4: trace_group<4, WITH_REFL, CHUNKED, GROUPED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
+    default: trace_group<5, WITH_REFL, CHUNKED, GROUPED>(sc, lds, cap, on, pos, refl, want_refl, e0, lit, alt, next, next_hit, cnt); break;
     }
 }
 
@@ -483,7 +508,7 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
                                                              RtStatsDev *stats)
 {
     extern __shared__ float4 lds[];
-    const int cap = fr.chunk;                         // pairs resident in LDS
+    const int cap = GROUPED ? 0 : fr.chunk;           // pairs resident in LDS
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -505,13 +530,9 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
     __shared__ int q_count[2];                        // [0] requests with a reflection ray, [1] without
     unsigned *const queue = reinterpret_cast<unsigned *>(lds + 2 * cap);   // aliases the camera table
     if (threadIdx.x == 0) q_count[0] = q_count[1] = 0;
-    if (!CHUNKED) stage<false>(sc, lds, cap, 0, sc.n_pairs, false, cam_pos);
-    // grouped layout: the group heads sit behind the queue (there is no camera table)
-    float4 *const heads = lds + 2 * cap + kQueueFloat4;
-    if constexpr (GROUPED) {
-        for (int h = threadIdx.x; h < 2 * ((sc.n_groups + 1) >> 1); h += kBlock) heads[h] = sc.heads[h];
-        __syncthreads();
-    }
+    // (grouped layout: the scene is read through the scalar cache, LDS holds the request queue only)
+    if (!CHUNKED && !GROUPED) stage<false>(sc, lds, cap, 0, sc.n_pairs, false, cam_pos);
+    else if (GROUPED) __syncthreads();                 // q_count
 
     // one record per path segment, read back deepest-first (runtime-indexed -> private memory)
     // LEVELS >= max_depth + 1 (the launcher picks the smallest instantiation that fits: the
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
     unsigned long long rec_lit[kRec], rec_alt[kRec];
 
     unsigned n_refl = 0, n_shadow = 0, n_hits = 0, n_lit = 0;
-    SweepCount cnt = {0u, 0u};
+    SweepCount cnt = {0u, 0u, 0u};
     V3 color = v3(0.0f, 0.0f, 0.0f);
 
     for (int s = 0; s < fr.spp; s++) {                                       // main.cpp:203
@@ -543,13 +564,13 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
             r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
             r.act[0] = in_image;
             if constexpr (GROUPED) {
-                sweep<1, CHUNKED, true>(sc, lds, heads, cap, in_image, cam_pos, r);
+                sweep<1, false, true>(sc, lds, cap, in_image, cam_pos, r);
             } else {
                 if (!CHUNKED) build_cam_table(lds, cap, sc.n_pairs, cam_pos);
                 sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
             }
             merge_planes<1>(sc, in_image, r);
-            if (in_image) { cnt.tests += 2u * r.pairs_run; cnt.gtests += 2u * r.heads_run; }
+            if (in_image) { cnt.tests += 2u * r.pairs_run; cnt.gtests += 2u * r.heads_run; cnt.cands += r.cand_run; }
             seg.o = r.o[0]; seg.d = r.d[0]; seg.dist = r.best[0]; seg.slot = r.slot[0]; seg.id = r.id[0];
             alive = in_image && r.slot[0] != INT_MIN;
         }
@@ -641,14 +662,16 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
                 // chunked sweeps contain workgroup barriers, so every wave must take the same path there
                 const bool any_refl = COMPACT ? (CHUNKED ? n_front > 0 : wave * 64 < n_front) : block_any<CHUNKED>(want_refl);
                 int e0 = 0;
-                if (any_refl) {
+                // a wave with no request does nothing (chunked sweeps hold workgroup barriers: all waves go)
+                if (!CHUNKED && !__any(w_on)) e0 = sc.n_emit;
+                else if (any_refl) {
                     const int ne = min(sc.n_emit, kMaxK - 1);
-                    trace_group_k<true, CHUNKED, GROUPED>(1 + ne, sc, lds, heads, cap, w_on, w_pos, w_dir, w_refl, 0, lit, alt, next, next_hit, cnt);
+                    trace_group_k<true, CHUNKED, GROUPED>(1 + ne, sc, lds, cap, w_on, w_pos, w_dir, w_refl, 0, lit, alt, next, next_hit, cnt);
                     e0 = ne;
                 }
                 while (e0 < sc.n_emit) {
                     const int ne = min(sc.n_emit - e0, kMaxK);
-                    trace_group_k<false, CHUNKED, GROUPED>(ne, sc, lds, heads, cap, w_on, w_pos, w_dir, false, e0, lit, alt, next, next_hit, cnt);
+                    trace_group_k<false, CHUNKED, GROUPED>(ne, sc, lds, cap, w_on, w_pos, w_dir, false, e0, lit, alt, next, next_hit, cnt);
                     e0 += ne;
                 }
                 if (COMPACT && w_on) {
@@ -740,9 +763,9 @@ __global__ __launch_bounds__(kBlock, (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : 
             if (lane == 0 && t) atomicAdd(dst[k], (unsigned long long)t);
         }
         // executed tests are counted by the lane that swept (under compaction not the pixel's own)
-        unsigned long long w[2] = {cnt.tests, cnt.gtests};
-        unsigned long long *wdst[2] = {&stats->sphere_tests_run, &stats->group_tests_run};
-        for (int k = 0; k < 2; k++) {
+        unsigned long long w[3] = {cnt.tests, cnt.gtests, cnt.cands};
+        unsigned long long *wdst[3] = {&stats->sphere_tests_run, &stats->group_tests_run, &stats->exact_tests_run};
+        for (int k = 0; k < 3; k++) {
             unsigned long long t = w[k];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
             if (lane == 0 && t) atomicAdd(wdst[k], t);
@@ -761,12 +784,11 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     if (tiles <= 0) return hipSuccess;
     const dim3 grid((tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
     const int n_pairs = scene.n_pairs;
-    const bool chunked = frame.chunk < n_pairs;
+    const bool chunked = !grouped && frame.chunk < n_pairs;
     const int cap = frame.chunk > 0 ? frame.chunk : 1;
-    // flat: pairs | camera table or queue;  grouped: pairs | queue | group heads
-    const size_t lds_bytes = grouped ? (size_t)(2 * cap + kQueueFloat4 + 2 * ((scene.n_groups + 1) / 2)) * sizeof(float4)
+    // flat: pairs | camera table or queue;  grouped: the queue only
+    const size_t lds_bytes = grouped ? (size_t)kQueueFloat4 * sizeof(float4)
                                      : (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
-    if (grouped && chunked) return hipErrorInvalidValue;     // the caller sizes grouped scenes to fit
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     const bool compact = n_pairs >= 24;
 #define RT_LAUNCH_G(C, P, S, L, F, G)                                                                                   \
