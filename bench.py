@@ -7,6 +7,10 @@ metric's "4K depth 5"), antialiased with the reference's 4 fixed samples per pix
 -a 1, raytracer_cpp/main.cpp:234).  With N ranks the frame is cut into N cost-balanced row bands
 (one per GPU) and the RGBA8 bands are gathered to rank 0 over RCCL: strong scaling.
 
+The sweep is the library default (RT_SWEEP_AUTO: the grouped sweep for this scene).  The roofline
+object prices the FLOPs of the tests that kernel executed; "roofline_flat" is the same frame through
+the flat every-ray-tests-every-sphere sweep, measured in the same run (N = 1).
+
 Renders are enqueued on a torch stream (rt_set_stream) so that kernel, gather and assembly order
 on the device without host round trips; the trace kernel's duration is measured per launch with HIP
 events on that stream over the timed region (rt_stats.kernel_ms_total).
@@ -29,6 +33,26 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 FLOP_PER_SPHERE_TEST = 15       # 3 sub + 5 (dot) + 5 (dot) + mul + sub to the reject
 FLOP_PER_PLANE_TEST = 5
+
+
+def profiled_traffic(path, kernel):
+    """HBM-side bytes per launch from a committed rocprofv3 PMC summary of this same command
+    (tools/pmc_profile.sh): FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's gfx950
+    correction doubles FETCH_SIZE for wide streaming reads -- here most of the traffic is 4-byte
+    private-memory (spill/record) accesses, a width the guide calls uncalibrated, so the uncorrected
+    sum is reported and the note says so.  None when the summary is not there."""
+    try:
+        rows, on = {}, False
+        for line in open(path):
+            if line.startswith('"# ') or line.startswith("# "):
+                if "vgpr,agpr" not in line:
+                    on = kernel in line
+            elif on and "," in line:
+                k, v = line.split(",")[:2]
+                rows[k] = v
+        return (float(rows["FETCH_SIZE"]) + float(rows["WRITE_SIZE"])) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(capi, width, height, depth, spp, kind, offsets=None):
@@ -119,7 +143,12 @@ def main():
     n_sph = sum(1 for o in objs if o.type == capi.RT_OBJ_SPHERE)
     n_pl = len(objs) - n_sph
     my_rays = st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
-    my_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
+    # FLOPs of the tests the kernel EXECUTED: for the flat sweep that is rays x spheres (SURVEY 8d's
+    # lower bound); the grouped sweep skips most of them and pays bounding-sphere tests instead (the
+    # same 15-FLOP line-distance expression), so its figure is what ran, never the brute-force count
+    my_flop = (st["sphere_tests_run"] + st["group_tests_run"]) * FLOP_PER_SPHERE_TEST + my_rays * n_pl * FLOP_PER_PLANE_TEST
+    brute_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
+    grouped = st["group_tests_run"] > 0
 
     params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=sweep)
     stream = torch.cuda.Stream(device=dev)
@@ -195,9 +224,32 @@ def main():
                          "traffic": None,
                          "kernel_ms": k0_ms,
                          "algorithmic_flop_per_launch": int(my_flop),
-                         "note": "15 FLOP x rays x spheres + 5 FLOP x rays x planes (SURVEY 8d lower bound); "
-                                 "HBM traffic is the framebuffer only (4 B/px)"},
+                         "kernel": "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)",
+                         "brute_force_equivalent_tflops": (brute_flop / (k0_ms * 1e-3)) / 1e12 if k0_ms > 0 else 0.0,
+                         "note": "15 FLOP x (ray,sphere) and (ray,group) tests EXECUTED + 5 FLOP x rays x planes; for the "
+                                 "flat sweep that equals SURVEY 8d's 15 x rays x spheres; brute_force_equivalent = that "
+                                 "count over this kernel's time; HBM traffic is the framebuffer only (4 B/px)"},
         }
+        if world == 1 and (args.scene, W, H, args.depth, args.spp, args.mode) == ("grid1k", 3840, 2160, 5, 4, "exact"):
+            prof = os.path.join(ROOT, "profiles", "r1", "v4_grouped_grid1k.csv" if grouped else "v4_flat_grid1k.csv")
+            tag = "trace_sweep_kernel<false, true, false, 6, false, %s>" % ("true" if grouped else "false")
+            out["roofline"]["traffic"] = profiled_traffic(prof, tag)
+            out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE + WRITE_SIZE, uncorrected) from "
+                                               + os.path.relpath(prof, ROOT) + "; the frame itself is 33 MB: the rest is private-memory "
+                                               "(register spill + per-segment record) traffic, served by L2 / Infinity Cache")
+        if world == 1 and grouped:
+            # the same frame through the flat sweep (north_star's every-ray-tests-every-sphere kernel)
+            pf = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=capi.RT_SWEEP_FLAT)
+            b = ctx.stats()
+            for _ in range(3):
+                ctx.render(pf)
+            a = ctx.stats()
+            f_ms = (a["kernel_ms_total"] - b["kernel_ms_total"]) / 3
+            f_ach = (brute_flop / (f_ms * 1e-3)) / 1e12
+            out["roofline_flat"] = {"bound": "valu_fp32", "achieved": f_ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": f_ach / PEAK_FP32_VALU_TFLOPS, "kernel_ms": f_ms, "mrays_per_s": my_rays / f_ms / 1e3,
+                                    "kernel": "trace_sweep_kernel (flat sweep)", "algorithmic_flop_per_launch": int(brute_flop),
+                                    "note": "same frame, RT_SWEEP_FLAT: 15 FLOP x rays x spheres + 5 FLOP x rays x planes"}
         out["config"]["frame_crc"] = int(frame.to(torch.int64).sum().item() & 0xFFFFFFFF)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind, offsets)
