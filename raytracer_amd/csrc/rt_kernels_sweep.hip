@@ -507,7 +507,7 @@ __device__ __forceinline__ V3 add_lights(const RtSceneDev &sc, V3 out, V3 pos, V
 // Same hits, same lights; the sum associates differently, so radiance agrees with the reference to
 // rounding (<= 1e-5 relative, tested at 1e-4), not bit for bit.
 template <bool CHUNKED, bool COMPACT, bool STATS, int LEVELS, bool FAST, bool GROUPED>
-__global__ __launch_bounds__(GROUPED ? 64 : kBlock, GROUPED ? RT_WAVES_PER_SIMD_GROUPED : (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_SMALL) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
+__global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, GROUPED ? RT_WAVES_PER_SIMD_GROUPED : (CHUNKED || COMPACT) ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_SMALL) void trace_sweep_kernel(RtSceneDev sc, rt_camera cam, RtFrameDev fr, RtSamples smp,
                                                              RtStatsDev *stats)
 {
     extern __shared__ float4 lds[];
@@ -520,7 +520,8 @@ __global__ __launch_bounds__(GROUPED ? 64 : kBlock, GROUPED ? RT_WAVES_PER_SIMD_
     const int tiles_y = (rows + 7) >> 3;
     // grouped sweep: nothing is shared between waves (no LDS scene copy, no compaction), so a
     // workgroup is a single wave and a finished tile frees its slot at once
-    const int tile = blockIdx.x * (GROUPED ? 1 : kWavesPerBlock) + wave;
+    // (the same goes for scenes of a few spheres, which do not compact: their LDS copy is tiny)
+    const int tile = blockIdx.x * ((GROUPED || (!CHUNKED && !COMPACT)) ? 1 : kWavesPerBlock) + wave;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x = tx * 8 + (lane & 7);
     const int yr = ty * 8 + (lane >> 3);
@@ -787,17 +788,19 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const int rows = frame.row_end - frame.row_begin;
     const int tiles = ((frame.width + 7) / 8) * ((rows + 7) / 8);
     if (tiles <= 0) return hipSuccess;
-    const dim3 grid(grouped ? tiles : (tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(grouped ? 64 : kBlock);
     const int n_pairs = scene.n_pairs;
     const bool chunked = !grouped && frame.chunk < n_pairs;
     const int cap = frame.chunk > 0 ? frame.chunk : 1;
-    // flat: pairs | camera table or queue;  grouped: none
-    const size_t lds_bytes = grouped ? 0
-                                     : (size_t)(2 * cap + (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4)) * sizeof(float4);
     // compaction costs three workgroup barriers per bounce level: worth it once sweeps are long
     // (and not in the grouped sweep at all: mixing the rays of four tiles widens the set of groups a
     // wave has to visit, which costs more than the idle lanes: 15.8 -> 14.2 ms on grid-1024)
     const bool compact = n_pairs >= 24 && !grouped;
+    // single-wave workgroups wherever waves share nothing that matters (stage() strides by kBlock: fewer than 64 pairs)
+    const bool one_wave = grouped || (!compact && !chunked);
+    // LDS: flat = pairs | camera table, which the request queue aliases when compacting; grouped = none
+    const int second = compact || chunked ? (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4) : 2 * cap;
+    const size_t lds_bytes = grouped ? 0 : (size_t)(2 * cap + second) * sizeof(float4);
+    const dim3 grid(one_wave ? tiles : (tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
 #define RT_LAUNCH_G(C, P, S, L, F, G)                                                                                   \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \
