@@ -306,6 +306,34 @@ def tiled_plane(origin, normal, white=None, black=None):
     return o
 
 
+def load_scene_file(path, width, height):
+    """The scene description of raytracer_amd/host/rt_scenefile.hpp: returns (Object array, Camera).
+    Numbers go through float32 exactly as the C++ loader's `float` reads do."""
+    items, cam = [], None
+    for lineno, line in enumerate(open(path), 1):
+        words = line.split("#", 1)[0].split()
+        if not words:
+            continue
+        kind, v = words[0], [float(np.float32(w)) for w in words[1:]]
+        if kind == "camera" and len(v) == 7:
+            cam = camera_init(v[0:3], v[3:6], v[6], width, height)
+        elif kind == "sphere" and len(v) in (11, 14):
+            items.append(sphere(material(v[4:7], v[7:10], v[10], v[11:14] if len(v) == 14 else (0, 0, 0)), v[0:3], v[3]))
+        elif kind == "tiledplane" and len(v) in (6, 20):
+            n = np.asarray(v[3:6], dtype=np.float32)
+            # glm::normalize: v * (1 / sqrt(dot)), dot = (xx + yy) + zz, all in float
+            d = np.float32(np.float32(n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+            n = n * (np.float32(1.0) / np.sqrt(d))
+            white = material(v[6:9], v[9:12], v[12]) if len(v) == 20 else None
+            black = material(v[13:16], v[16:19], v[19]) if len(v) == 20 else None
+            items.append(tiled_plane(v[0:3], [float(x) for x in n], white, black))
+        else:
+            raise ValueError(f"{path}:{lineno}: bad statement {line.strip()!r}")
+    if cam is None or not items:
+        raise ValueError(f"{path}: needs a camera and at least one object")
+    return objects(items), cam
+
+
 def objects(items):
     arr = (Object * len(items))()
     for i, it in enumerate(items):

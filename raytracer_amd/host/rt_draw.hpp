@@ -24,6 +24,8 @@ struct DrawSceneError : std::runtime_error {
 struct DrawSceneOptions {
     int maxDepth = 5;           // MAX_DEPTH, main.cpp:16
     int device = 0;
+    int mode = RT_MODE_EXACT;   // RT_MODE_FAST: radiance to rounding instead of bit-identical
+    int sweep = RT_SWEEP_AUTO;  // RT_SWEEP_FLAT / RT_SWEEP_GROUPED: same image either way
     double *kernelMs = nullptr; // optional: device time of the trace kernel
 };
 
@@ -52,7 +54,8 @@ inline void DrawScene(Bitmap *pBitmap, int partitions, bool antialias, const Dra
     p.max_depth = opt.maxDepth;
     p.spp = antialias ? 4 : 1;                 // main.cpp:200
     p.outputs = RT_OUT_RGBA8;
-    p.mode = RT_MODE_EXACT;
+    p.mode = opt.mode;
+    p.sweep = opt.sweep;
     if ((rc = rt_render(ctx, &p)) != RT_OK) fail(rc);
     if (opt.kernelMs) {
         rt_stats st{};

@@ -1,11 +1,13 @@
 // rt_main.cpp -- the host program: counterpart of raytracer_cpp/main.cpp:21-63,230-258 on top of the
 // MI355X library.  Same options (-p/--partitions, -a/--antialiased), same scene, same "Time:" line,
-// same image.bmp.  Extra options select the size, depth, device and output path.
+// same image.bmp.  Extra options select the size, depth, device, output path, a scene file
+// (rt_scenefile.hpp) instead of InitScene's scene, and the library's mode / sweep.
 #include <chrono>
 #include <iostream>
 
 #include "rt_cmdline.hpp"
 #include "rt_draw.hpp"
+#include "rt_scenefile.hpp"
 
 std::vector<std::shared_ptr<SceneObject>> sceneObjects;
 std::shared_ptr<Camera> pCamera;
@@ -43,6 +45,9 @@ int main(int argc, char **argv)
     parser.set_optional<int>("d", "depth", 5, "MAX_DEPTH");
     parser.set_optional<int>("g", "gpu", 0, "HIP device");
     parser.set_optional<std::string>("o", "output", "image.bmp", "BMP file to write");
+    parser.set_optional<std::string>("s", "scene", "", "scene description file (default: the reference's InitScene scene)");
+    parser.set_optional<int>("m", "mode", 0, "0 = bit-identical to the reference, 1 = fast (radiance to rounding)");
+    parser.set_optional<int>("w", "sweep", 0, "0 = auto, 1 = flat (every ray tests every sphere), 2 = grouped");
     if (!parser.run()) return 2;
 
     const int partitions = parser.get<int>("p");
@@ -55,11 +60,21 @@ int main(int argc, char **argv)
 
     Bitmap *pBitmap = CreateBitmap(width, height);
     ClearBitmap(pBitmap, Color{127, 127, 127});
-    InitScene(width, height);
+    const std::string sceneFile = parser.get<std::string>("s");
+    try {
+        if (sceneFile.empty()) InitScene(width, height);
+        else LoadSceneFile(sceneFile, width, height);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        DestroyBitmap(pBitmap);
+        return 2;
+    }
 
     DrawSceneOptions opt;
     opt.maxDepth = parser.get<int>("d");
     opt.device = parser.get<int>("g");
+    opt.mode = parser.get<int>("m");
+    opt.sweep = parser.get<int>("w");
     double kernelMs = 0.0;
     opt.kernelMs = &kernelMs;
 

@@ -97,3 +97,47 @@ def test_host_program_writes_reference_image(tmp_path, args, key):
     assert r.stdout.startswith("Time: ")
     data = open(tmp_path / "image.bmp", "rb").read()
     assert hashlib.md5(data).hexdigest() == pins["bmp_md5"][key]
+
+
+SCENE_TXT = """# three balls, a light and a tinted floor
+camera      0 5 9   0 -0.55 -1   55
+sphere      0 1.5 0 1.5     0.7 0.1 0.1   0.9 0.1 0.1   0.5
+sphere      -3 1 1.5 1      0.1 0.6 0.2   0.3 0.9 0.3   0.25
+tiledplane  0 0 0   0 2 0     1 0.9 0.8  1 1 1  0.4     0.1 0.1 0.2  0 0 0  0.7
+sphere      2.5 0.6 2 0.6   1 1 1   0 0 0   0    1 0.8 0.6     # emits
+sphere      -6 9 6 0.5      0 0 0   0 0 0   0    1 1 1
+"""
+
+
+def test_scene_file_parsers_agree_and_reject_garbage(capi, tmp_path):
+    path = tmp_path / "scene.txt"
+    path.write_text(SCENE_TXT)
+    objs, cam = capi.load_scene_file(str(path), 320, 200)
+    assert len(objs) == 5 and [o.type for o in objs] == [0, 0, 1, 0, 0]
+    assert list(objs[2].b) == [0.0, 1.0, 0.0] and abs(objs[2].mat2.reflectance - 0.7) < 1e-6
+    assert list(objs[3].mat.emissive) == [1.0, np.float32(0.8), np.float32(0.6)]
+    (tmp_path / "bad.txt").write_text("camera 0 0 0 0 0 -1 60\nsphere 1 2 3\n")
+    with pytest.raises(ValueError):
+        capi.load_scene_file(str(tmp_path / "bad.txt"), 8, 8)
+    r = subprocess.run([MAIN, "-s", str(tmp_path / "bad.txt")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "bad.txt:2" in r.stderr
+    r = subprocess.run([MAIN, "-s", str(tmp_path / "missing.txt")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-w", "1"], ["-w", "2"]])
+def test_host_program_renders_scene_file(capi, oracle, tmp_path, extra):
+    """rt_main -s FILE: the scene goes through the host's Sphere/TiledPlane/Camera classes; the BMP
+    must be the one the oracle renders from the Python parse of the same file."""
+    path = tmp_path / "scene.txt"
+    path.write_text(SCENE_TXT)
+    w, h = 333, 211
+    r = subprocess.run([MAIN, "-s", str(path), "-W", str(w), "-H", str(h), "-a", "1", "-o", "out.bmp"] + extra,
+                       cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    objs, cam = capi.load_scene_file(str(path), w, h)
+    rgb, _, _ = oracle.render(objs, cam, capi.render_params(w, h, 5, 4), threads=8)
+    want = tmp_path / "want.bmp"
+    oracle.write_bmp(str(want), rgb)
+    assert open(tmp_path / "out.bmp", "rb").read() == open(want, "rb").read()
