@@ -129,6 +129,17 @@ typedef struct rt_render_params {
     int32_t mode;           /* RT_MODE_*                                                          */
     int32_t collect_stats;  /* non-zero: count rays/tests in-kernel (slower; rt_get_stats)        */
     int32_t sweep;          /* RT_SWEEP_*                                                         */
+    /* Options taken from raytracer_win (ray generation and accumulation only; TraceRay is unchanged).
+     * All zero = raytracer_cpp's behaviour. */
+    const float *lens_offsets; /* thin-lens depth of field, raytracer_win/camera.h:147-173: 2*spp floats,
+                                  the lens-plane offset (along right, along up) of each sample -- what the
+                                  reference draws with glm::circularRand(0.14f); NULL = pinhole camera  */
+    float focal_length;     /* glm::length(focalPoint - position), camera.h:162; used with lens_offsets */
+    int32_t accumulate;     /* non-zero: progressive running mean, raytracer_win/main.cpp:292-314:
+                               float plane = (plane * k1 + vec4(color, 1)) * (1 / (k1 + 1)), k1 =
+                               accum_index; needs RT_OUT_F32X4, whose w then is that mean of 1 instead
+                               of the ray count; RGBA8 is the quantised mean (main.cpp:44-72)          */
+    int32_t accum_index;    /* currentSample: 0 for the first frame (which ignores the old content)   */
 } rt_render_params;
 
 typedef struct rt_stats {

@@ -40,16 +40,19 @@ def lib():
     if _lib is None:
         _lib = load_oracle()
         _lib.orc_render.restype = None
+        _lib.orc_lens_ray.restype = None
         _lib.orc_trace.restype = None
         _lib.orc_trace_samples.restype = None
     return _lib
 
 
-def render(objs, cam, params, verbatim=False, threads=1, want_rgb8=True, want_f32=True, want_stats=False):
+def render(objs, cam, params, verbatim=False, threads=1, want_rgb8=True, want_f32=True, want_stats=False, f32_in=None):
     """orc_render over full-image buffers; returns (rgb8 HxWx3, f32 HxWx4, stats dict|None)."""
     h, w = params.height, params.width
     rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 else None
     f32 = np.zeros((h, w, 4), dtype=np.float32) if want_f32 else None
+    if f32_in is not None:      # progressive accumulation continues from an earlier frame's float plane
+        f32 = np.array(f32_in, dtype=np.float32, copy=True).reshape(h, w, 4)
     st = OrcStats() if want_stats else None
     lib().orc_render(objs, C.c_int(len(objs)), C.byref(cam), C.byref(params), C.c_int(int(verbatim)),
                      C.c_int(threads),
@@ -70,6 +73,14 @@ def trace_samples(objs, cam, max_depth, sxy):
                             sxy.ctypes.data_as(C.c_void_p), C.c_int(sxy.shape[0]),
                             out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def lens_ray(cam, focal_length, lens, sxy):
+    """orc_lens_ray: (origin, direction) of the thin-lens ray."""
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    lib().orc_lens_ray(C.byref(cam), C.c_float(focal_length), C.c_float(lens[0]), C.c_float(lens[1]),
+                       C.c_float(sxy[0]), C.c_float(sxy[1]), o, d)
+    return list(o), list(d)
 
 
 def write_bmp(path, rgb8):

@@ -84,6 +84,29 @@ void orc_world_ray(const rt_camera *cam, float sx, float sy, float out[3])
     out[0] = dir.x; out[1] = dir.y; out[2] = dir.z;
 }
 
+/* raytracer_win/camera.h:147-173 (thin-lens GetWorldRay) with the lens-plane offset handed in instead
+ * of drawn from glm::circularRand(0.14f) (:154): origin = the lens point, direction = towards the
+ * point of the pinhole ray at focus distance (focal_length - 1) / |dir|, focal_length =
+ * glm::length(focalPoint - position) (:162).  filmWidth/filmHeight are image_width/image_height. */
+void orc_lens_ray(const rt_camera *cam, float focal_length, float lens_x, float lens_y, float sx, float sy,
+                  float out_o[3], float out_d[3])
+{
+    v3 dir = v3_from(cam->view_direction);                                  /* :156 */
+    float x = ((sx * 2.0f) / cam->image_width) - 1.0f;                      /* :157 */
+    float y = ((sy * 2.0f) / cam->image_height) - 1.0f;                     /* :158 */
+    v3 right = v3_from(cam->right), up = v3_from(cam->up), pos = v3_from(cam->position);
+    dir = v3_add(dir, v3_scale(right, cam->half_angle * cam->aspect_ratio * x));   /* :162 */
+    dir = v3_sub(dir, v3_scale(up, cam->half_angle * y));                   /* :163 */
+    float ft = (focal_length - 1.0f) / sqrtf(v3_dot(dir, dir));             /* :165, glm::length = sqrt(dot) */
+    v3 focus = v3_add(pos, v3_scale(dir, ft));                              /* :166 */
+    v3 lens = pos;                                                          /* :168 */
+    lens = v3_add(lens, v3_scale(right, lens_x));                           /* :169 */
+    lens = v3_add(lens, v3_scale(up, lens_y));                              /* :170 */
+    dir = v3_normalize(v3_sub(focus, lens));                                /* :171 */
+    out_o[0] = lens.x; out_o[1] = lens.y; out_o[2] = lens.z;
+    out_d[0] = dir.x; out_d[1] = dir.y; out_d[2] = dir.z;
+}
+
 /* ---- primitives --------------------------------------------------------------------------- */
 
 /* glm/gtx/intersect.inl:105-123, given the already normalised direction */
@@ -330,14 +353,27 @@ static void *render_rows(void *arg)
             memset(&px_st, 0, sizeof px_st);
             for (int s = 0; s < p->spp; s++) {                            /* :203-209 */
                 float sx = (float)x + pat[2 * s], sy = (float)y + pat[2 * s + 1];
-                float d[3];
-                orc_world_ray(j->cam, sx, sy, d);
+                float d[3], o[3] = {cpos.x, cpos.y, cpos.z};
+                if (p->lens_offsets)
+                    orc_lens_ray(j->cam, p->focal_length, p->lens_offsets[2 * s], p->lens_offsets[2 * s + 1], sx, sy, o, d);
+                else
+                    orc_world_ray(j->cam, sx, sy, d);
                 px_st.primary_rays++;
-                color = v3_add(color, trace(j->objs, j->n, cpos, v3_from(d), 0, p->max_depth, j->verbatim, &px_st));
+                color = v3_add(color, trace(j->objs, j->n, v3_from(o), v3_from(d), 0, p->max_depth, j->verbatim, &px_st));
             }
             color = v3_scale(color, 1.0f / (float)p->spp);                /* :210 */
             size_t idx = (size_t)p->width * (size_t)y + (size_t)x;
-            if (j->f32x4) {
+            if (p->accumulate && j->f32x4) {
+                /* raytracer_win/main.cpp:292-314: bufferVal = ((bufferVal * k1) + vec4(color, 1)) * k2 */
+                const float k1 = (float)p->accum_index, k2 = 1.f / (k1 + 1.f);
+                float *o = j->f32x4 + 4 * idx;
+                const float in[4] = {color.x, color.y, color.z, 1.0f};
+                /* sample 0 starts from the zero-initialised buffer of InitMaps (:105) */
+                for (int k = 0; k < 4; k++) o[k] = (((p->accum_index == 0 ? 0.0f : o[k]) * k1) + in[k]) * k2;
+                /* CopyTargetToBitmap (:44-72) shows the mean: clamp(0,1) then *255 -- the same bytes as
+                 * the *255 / clamp(0,255) below for every input, NaN included */
+                color = v3_make(o[0], o[1], o[2]);
+            } else if (j->f32x4) {
                 float *o = j->f32x4 + 4 * idx;
                 /* w = rays this pixel cost: primary + reflection + pruned shadow rays */
                 o[0] = color.x; o[1] = color.y; o[2] = color.z;

@@ -53,6 +53,8 @@ void orc_trace(const rt_object *objs, int n, const float orig[3], const float di
  * the 1/spp scale, w = number of rays the pixel cost
  * (primary + reflection + pruned shadow rays, all samples).  Rows [row_begin,row_end) are rendered into full-image-indexed buffers.
  * threads >= 1 interleaves rows like the reference's partitions. */
+void orc_lens_ray(const rt_camera *cam, float focal_length, float lens_x, float lens_y, float sx, float sy,
+                  float out_o[3], float out_d[3]);
 void orc_render(const rt_object *objs, int n, const rt_camera *cam, const rt_render_params *p,
                 int verbatim, int threads, uint8_t *rgb8, float *f32x4, orc_stats *st);
 /* Radiance of individual samples (sx, sy in pixel units) -- for sparse-pixel fixtures. */

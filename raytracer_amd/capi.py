@@ -47,7 +47,9 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
                 ("spp", C.c_int32), ("sample_offsets", C.POINTER(C.c_float)),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("outputs", C.c_int32),
-                ("mode", C.c_int32), ("collect_stats", C.c_int32), ("sweep", C.c_int32)]
+                ("mode", C.c_int32), ("collect_stats", C.c_int32), ("sweep", C.c_int32),
+                ("lens_offsets", C.POINTER(C.c_float)), ("focal_length", C.c_float),
+                ("accumulate", C.c_int32), ("accum_index", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -182,7 +184,9 @@ def stratified_offsets(spp=16, seed=0x16A11CE):
 
 
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
-                  mode=RT_MODE_EXACT, stats=False, sweep=0):
+                  mode=RT_MODE_EXACT, stats=False, sweep=0, lens=None, focal_length=0.0, accumulate=None):
+    """lens: spp x 2 lens-plane offsets (thin-lens depth of field) with focal_length; accumulate: k
+    (currentSample) for the progressive running mean, None = overwrite."""
     p = RenderParams()
     p.width, p.height, p.max_depth, p.spp = width, height, max_depth, spp
     keep = None
@@ -193,7 +197,15 @@ def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, ou
     if rows is not None:
         p.row_begin, p.row_end = rows
     p.outputs, p.mode, p.collect_stats, p.sweep = outputs, mode, int(stats), sweep
-    p._keep = keep  # keep the offsets array alive as long as the struct
+    keep_lens = None
+    if lens is not None:
+        keep_lens = np.ascontiguousarray(lens, dtype=np.float32).reshape(-1)
+        assert keep_lens.size == 2 * spp
+        p.lens_offsets = keep_lens.ctypes.data_as(C.POINTER(C.c_float))
+        p.focal_length = float(focal_length)
+    if accumulate is not None:
+        p.accumulate, p.accum_index = 1, int(accumulate)
+    p._keep = (keep, keep_lens)  # keep the arrays alive as long as the struct
     return p
 
 

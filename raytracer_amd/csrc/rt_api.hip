@@ -569,6 +569,12 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
     if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown output flags 0x%x", outputs);
+    if (p->accumulate && !(outputs & RT_OUT_F32X4))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: accumulate needs the RT_OUT_F32X4 plane (it holds the running mean)");
+    if (p->accumulate && p->accum_index < 0)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: accum_index %d is negative", p->accum_index);
+    if (ctx->simple_kernel && (p->lens_offsets || p->accumulate))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: the transcription kernel (RT_AMD_KERNEL=simple) has no lens/accumulate options");
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)p->width * (size_t)(y1 - y0);
@@ -592,6 +598,11 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     fr.max_depth = p->max_depth;
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
+    fr.lens_on = p->lens_offsets != nullptr;
+    fr.focal_length = p->focal_length;
+    fr.accumulate = p->accumulate != 0;
+    fr.k1 = (float)p->accum_index;                           // raytracer_win/main.cpp:292-293
+    fr.k2 = 1.f / (fr.k1 + 1.f);
     bool grouped = false;
     // (scenes of a few dozen spheres gain nothing from grouping: they always take the flat sweep)
     if (p->sweep != RT_SWEEP_FLAT && !ctx->simple_kernel && ctx->scene.n_spheres >= 64) {
@@ -611,6 +622,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     RtSamples smp;
     memset(&smp, 0, sizeof smp);
     memcpy(smp.xy, p->sample_offsets ? p->sample_offsets : kRefPattern, sizeof(float) * 2 * (size_t)p->spp);
+    if (p->lens_offsets) memcpy(smp.lens, p->lens_offsets, sizeof(float) * 2 * (size_t)p->spp);
 
     RtStatsDev *sdev = nullptr;
     if (p->collect_stats) {

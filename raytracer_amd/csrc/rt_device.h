@@ -75,6 +75,10 @@ struct RtFrameDev {
     int32_t max_depth, spp;
     float inv_spp;
     int32_t chunk;        // LDS capacity per pass: sphere PAIRS (sweep kernel) / spheres (simple kernel)
+    int32_t lens_on;      // thin-lens ray generation (raytracer_win/camera.h:147-173), offsets in RtSamples::lens
+    float focal_length;
+    int32_t accumulate;   // running mean into f32x4 (raytracer_win/main.cpp:292-314)
+    float k1, k2;         // currentSample and 1 / (currentSample + 1)
 };
 
 struct RtStatsDev {
@@ -85,6 +89,7 @@ struct RtStatsDev {
 
 struct RtSamples {
     float xy[2 * RT_MAX_SPP];
+    float lens[2 * RT_MAX_SPP];   // lens-plane offsets (along right, along up) when RtFrameDev::lens_on
 };
 
 // kernel launchers

@@ -565,12 +565,27 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
             d = d + cam_right * (cam.half_angle * cam.aspect_ratio * px);
             d = d - cam_up * (cam.half_angle * py);
             RaySet<1> r;
-            r.o[0] = cam_pos;
-            r.d[0] = normalize(d);
+            if (fr.lens_on) {
+                // thin lens, raytracer_win/camera.h:160-171: aim at the pinhole ray's point at focus
+                // distance from the sample's point on the lens
+                const float ft = (fr.focal_length - 1.0f) / sqrtf(dot(d, d));
+                const V3 focus = cam_pos + d * ft;
+                V3 lens = cam_pos;
+                lens = lens + cam_right * smp.lens[2 * s];
+                lens = lens + cam_up * smp.lens[2 * s + 1];
+                r.o[0] = lens;
+                r.d[0] = normalize(focus - lens);
+            } else {
+                r.o[0] = cam_pos;
+                r.d[0] = normalize(d);
+            }
             r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
             r.act[0] = in_image;
             if constexpr (GROUPED) {
-                sweep<1, false, true>(sc, lds, cap, in_image, cam_pos, r);
+                sweep<1, false, true>(sc, lds, cap, in_image, r.o[0], r);
+            } else if (fr.lens_on) {
+                // every lane has its own origin: the general sweep (the camera table assumes one origin)
+                sweep<1, CHUNKED, false>(sc, lds, cap, in_image, r.o[0], r);
             } else {
                 if (!CHUNKED) build_cam_table(lds, cap, sc.n_pairs, cam_pos);
                 sweep_primary<CHUNKED>(sc, lds, cap, in_image, cam_pos, r);
@@ -755,7 +770,15 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
     if (in_image) {
         color = color * fr.inv_spp;                                          // main.cpp:210
         const size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
-        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, (float)(fr.spp + n_refl + n_shadow));
+        float w = (float)(fr.spp + n_refl + n_shadow);
+        if (fr.accumulate) {
+            // raytracer_win/main.cpp:314: bufferVal = ((bufferVal * k1) + vec4(color, 1)) * k2; sample 0
+            // starts from the zero-initialised buffer (:105)
+            const float4 old = fr.k1 == 0.0f ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : fr.f32x4[idx];
+            color = ((v3(old.x, old.y, old.z) * fr.k1) + color) * fr.k2;
+            w = ((old.w * fr.k1) + 1.0f) * fr.k2;
+        }
+        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, w);
         if (fr.rgba8)
             fr.rgba8[idx] = to_u8(color.x) | (to_u8(color.y) << 8) | (to_u8(color.z) << 16) | 0xff000000u;
     }

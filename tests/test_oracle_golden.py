@@ -216,3 +216,37 @@ def test_scene_generators_and_sparse_radiance(oracle, capi):
         n = 192 if s["n"] < 2000 else 24          # the 16k scene costs ~0.1 s per path on one core
         rad = oracle.trace_samples(objs, cam, s["depth"], sxy[:n])
         assert same_bits(rad.reshape(-1), fl(s["radiance"])[: 3 * n]), name
+
+
+def test_thin_lens_ray_kat(oracle, capi):
+    """orc_lens_ray against raytracer_win's Camera::GetWorldRay (camera.h:147-173): 200 rays of the
+    reference header itself, with the lens offset its glm::circularRand(0.14f) drew for each."""
+    rows = load("lens_rays.json")["rows"]
+    assert len(rows) == 200
+    for r in rows:
+        c = fl(r["camera"])
+        cam = capi.Camera()
+        cam.position[:], cam.view_direction[:], cam.right[:], cam.up[:] = c[0:3], c[3:6], c[6:9], c[9:12]
+        cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height = c[12], c[13], c[14], c[15]
+        o, d = oracle.lens_ray(cam, float(c[16]), [float(v) for v in fl(r["lens"])], [float(v) for v in fl(r["s"])])
+        assert same_bits(o, fl(r["o"])) and same_bits(d, fl(r["d"])), r["seed"]
+        assert abs(np.hypot(*fl(r["lens"])) - 0.14) < 1e-6
+
+
+def test_accumulation_is_a_running_mean(oracle, capi):
+    """raytracer_win/main.cpp:292-314 on the default scene: three accumulated frames with different
+    sub-pixel samples equal the float-by-float recurrence applied to the three single frames."""
+    w, h = 64, 48
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    rng = np.random.default_rng(3)
+    acc = np.zeros((h, w, 4), dtype=np.float32)
+    want = np.zeros((h, w, 4), dtype=np.float32)
+    for k in range(3):
+        off = rng.random((1, 2)).astype(np.float32)
+        _, single, _ = oracle.render(objs, cam, capi.render_params(w, h, 5, 1, offsets=off), threads=4)
+        single[..., 3] = 1.0
+        k1 = np.float32(k)
+        want = ((want * k1) + single) * (np.float32(1.0) / (k1 + np.float32(1.0)))
+        rgb, acc, _ = oracle.render(objs, cam, capi.render_params(w, h, 5, 1, offsets=off, accumulate=k), threads=4, f32_in=acc)
+    assert same_bits(acc, want)
+    assert np.array_equal(rgb, np.clip(want[..., :3] * np.float32(255.0), 0, 255).astype(np.uint8))
