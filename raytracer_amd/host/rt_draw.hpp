@@ -3,6 +3,8 @@
 // uploaded, traced on the device and the frame lands in Bitmap::pData.  There is no CPU path: a
 // failure of any rt_* call is reported through DrawSceneError and nothing is drawn.
 #pragma once
+#include <cmath>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -26,8 +28,25 @@ struct DrawSceneOptions {
     int device = 0;
     int mode = RT_MODE_EXACT;   // RT_MODE_FAST: radiance to rounding instead of bit-identical
     int sweep = RT_SWEEP_AUTO;  // RT_SWEEP_FLAT / RT_SWEEP_GROUPED: same image either way
-    double *kernelMs = nullptr; // optional: device time of the trace kernel
+    double *kernelMs = nullptr; // optional: device time of the trace kernel (summed over frames)
+    // raytracer_win's progressive mode (raytracer_win/main.cpp:280-327, camera.h:147-173): `frames`
+    // single-sample frames folded into a running mean, each with its own sub-pixel jitter and, when
+    // lensRadius > 0, its own point on the rim of the lens (what glm::circularRand(radius) draws).
+    // The reference seeds rand() from the clock; here the sequence is the scene generators' LCG so a
+    // run can be reproduced.  frames = 1, lensRadius = 0 is raytracer_cpp's single frame.
+    int frames = 1;
+    float lensRadius = 0.0f;
+    float focalLength = 0.0f;   // glm::length(focalPoint - position)
+    uint32_t seed = 0x5EED1E25u;
 };
+
+namespace rt_detail {
+inline float lcg_unit(uint32_t &s)
+{
+    s = s * 1664525u + 1013904223u;
+    return (float)(s >> 8) * (1.0f / 16777216.0f);
+}
+} // namespace rt_detail
 
 // `partitions` is the reference's CPU thread count; the device schedules its own waves, so the
 // value only has to be positive.  `antialias` selects the reference's 4 fixed sub-pixel samples.
@@ -52,16 +71,40 @@ inline void DrawScene(Bitmap *pBitmap, int partitions, bool antialias, const Dra
     p.width = pBitmap->width;
     p.height = pBitmap->height;
     p.max_depth = opt.maxDepth;
-    p.spp = antialias ? 4 : 1;                 // main.cpp:200
-    p.outputs = RT_OUT_RGBA8;
     p.mode = opt.mode;
     p.sweep = opt.sweep;
-    if ((rc = rt_render(ctx, &p)) != RT_OK) fail(rc);
-    if (opt.kernelMs) {
-        rt_stats st{};
-        if ((rc = rt_get_stats(ctx, &st)) != RT_OK) fail(rc);
-        *opt.kernelMs = st.kernel_ms;
+    const bool progressive = opt.frames > 1 || opt.lensRadius > 0.0f;
+    double kernelMs = 0.0;
+    uint32_t s = opt.seed;
+    for (int k = 0; k < (opt.frames > 0 ? opt.frames : 1); k++) {
+        float jitter[2], lens[2];
+        if (progressive) {
+            p.spp = 1;
+            jitter[0] = rt_detail::lcg_unit(s);
+            jitter[1] = rt_detail::lcg_unit(s);
+            p.sample_offsets = jitter;
+            p.outputs = RT_OUT_RGBA8 | RT_OUT_F32X4;
+            p.accumulate = 1;
+            p.accum_index = k;
+            if (opt.lensRadius > 0.0f) {
+                const double a = 6.283185307179586 * (double)rt_detail::lcg_unit(s);
+                lens[0] = (float)std::cos(a) * opt.lensRadius;
+                lens[1] = (float)std::sin(a) * opt.lensRadius;
+                p.lens_offsets = lens;
+                p.focal_length = opt.focalLength;
+            }
+        } else {
+            p.spp = antialias ? 4 : 1;             // main.cpp:200
+            p.outputs = RT_OUT_RGBA8;
+        }
+        if ((rc = rt_render(ctx, &p)) != RT_OK) fail(rc);
+        if (opt.kernelMs) {
+            rt_stats st{};
+            if ((rc = rt_get_stats(ctx, &st)) != RT_OK) fail(rc);
+            kernelMs += st.kernel_ms;
+        }
     }
+    if (opt.kernelMs) *opt.kernelMs = kernelMs;
     const size_t bytes = (size_t)pBitmap->width * (size_t)pBitmap->height * sizeof(Color);
     if ((rc = rt_download_framebuffer(ctx, pBitmap->pData, bytes, RT_FMT_RGB8)) != RT_OK) fail(rc);
     rt_destroy(ctx);

@@ -46,6 +46,9 @@ int main(int argc, char **argv)
     parser.set_optional<int>("g", "gpu", 0, "HIP device");
     parser.set_optional<std::string>("o", "output", "image.bmp", "BMP file to write");
     parser.set_optional<std::string>("s", "scene", "", "scene description file (default: the reference's InitScene scene)");
+    parser.set_optional<int>("f", "frames", 1, "progressive mode: this many jittered single-sample frames, running mean");
+    parser.set_optional<float>("l", "lens", 0.0f, "thin-lens radius (depth of field), e.g. 0.14; needs --focus");
+    parser.set_optional<float>("F", "focus", 0.0f, "distance from the camera to the focal point");
     parser.set_optional<int>("m", "mode", 0, "0 = bit-identical to the reference, 1 = fast (radiance to rounding)");
     parser.set_optional<int>("w", "sweep", 0, "0 = auto, 1 = flat (every ray tests every sphere), 2 = grouped");
     if (!parser.run()) return 2;
@@ -73,6 +76,9 @@ int main(int argc, char **argv)
     DrawSceneOptions opt;
     opt.maxDepth = parser.get<int>("d");
     opt.device = parser.get<int>("g");
+    opt.frames = parser.get<int>("f");
+    opt.lensRadius = parser.get<float>("l");
+    opt.focalLength = parser.get<float>("F");
     opt.mode = parser.get<int>("m");
     opt.sweep = parser.get<int>("w");
     double kernelMs = 0.0;

@@ -141,3 +141,32 @@ def test_host_program_renders_scene_file(capi, oracle, tmp_path, extra):
     want = tmp_path / "want.bmp"
     oracle.write_bmp(str(want), rgb)
     assert open(tmp_path / "out.bmp", "rb").read() == open(want, "rb").read()
+
+
+def _lcg_unit(state):
+    state[0] = (state[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+    return np.float32(state[0] >> 8) * np.float32(1.0 / 16777216.0)
+
+
+@pytest.mark.gpu
+def test_host_program_progressive_depth_of_field(capi, oracle, tmp_path):
+    """rt_main --frames 5 --lens 0.14 --focus 10: raytracer_win's progressive mode (jittered single
+    samples, a lens point per frame, running mean) on the default scene; the BMP equals the oracle's
+    for the same documented LCG sequence."""
+    import math
+    w, h, frames = 320, 200, 5
+    r = subprocess.run([MAIN, "-W", str(w), "-H", str(h), "-f", str(frames), "-l", "0.14", "-F", "10", "-o", "dof.bmp"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    st, acc = [0x5EED1E25], np.zeros((h, w, 4), dtype=np.float32)
+    for k in range(frames):
+        jit = [_lcg_unit(st), _lcg_unit(st)]
+        a = 6.283185307179586 * float(_lcg_unit(st))
+        lens = [np.float32(math.cos(a)) * np.float32(0.14), np.float32(math.sin(a)) * np.float32(0.14)]
+        p = capi.render_params(w, h, 5, 1, offsets=[jit], lens=[lens], focal_length=10.0, accumulate=k,
+                               outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4)
+        rgb, acc, _ = oracle.render(objs, cam, p, threads=8, f32_in=acc)
+    want = tmp_path / "want.bmp"
+    oracle.write_bmp(str(want), rgb)
+    assert open(tmp_path / "dof.bmp", "rb").read() == open(want, "rb").read()
