@@ -35,7 +35,7 @@
 #define RT_MAX_PLANES 16
 #define RT_MAX_EMITTERS 64
 #define RT_GROUP_PAIRS 8      // pair records per group (16 spheres)
-#define RT_SUPER_GROUPS 16     // groups per super-group (256 spheres)
+#define RT_SUPER_GROUPS 8      // groups per super-group (128 spheres)
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
