@@ -1,10 +1,16 @@
 // rt_kernels_sweep.hip -- the production trace kernel for gfx950 (RT_MODE_EXACT and RT_MODE_FAST).
 // Compile with -ffp-contract=off (the explicit fma()s below are kept).
 //
-// Geometry: one wave64 = one 8x8 pixel tile, one 256-thread workgroup = four tiles sharing ONE LDS
-// copy of the sphere list.  Spheres are stored in PAIRS, 32 B per pair,
+// Geometry: one wave64 = one 8x8 pixel tile.  Spheres are stored in PAIRS, 32 B per pair,
 //     A = {cx0, cx1, cy0, cy1}   B = {cz0, cz1, -r0^2, -r1^2}
-// so that a broadcast ds_read_b128 x2 feeds v_pk_*_f32 instructions that test two spheres at once.
+// so that one record feeds v_pk_*_f32 instructions that test two spheres at once.  Two sweeps:
+//   FLAT     every ray against every sphere.  A 256-thread workgroup = four tiles sharing ONE LDS
+//            copy of the list (broadcast ds_read_b128 x2 per pair), streamed in chunks when it
+//            does not fit; scenes of a few spheres run as single-wave workgroups.
+//   GROUPED  groups of 16 spheres under two levels of bounding spheres; a wave visits a group only
+//            if the line of one of its rays can touch the bound.  Records come through wave-uniform
+//            scalar loads, workgroups are single waves, no LDS (see group_mask()).
+// Both give the same bits.
 //
 // Per path segment a lane needs the nearest hit of 1 + E rays that all leave the same surface point
 // `pos` (the reflection ray and one shadow ray per emissive object, main.cpp:108 and :112-151).
@@ -22,7 +28,7 @@
 // The result is bit-identical to the reference while the hot loop runs ~6 VALU lane-ops per test
 // instead of the ~17 of the straight transcription (rt_kernels_exact.hip, kept for A/B).
 //
-// Ray compaction: lanes of a tile die at different depths, so after the primary sweep the live
+// Ray compaction (flat sweep): lanes of a tile die at different depths, so after the primary sweep the live
 // hit points of the whole workgroup (4 tiles) are packed into a dense request queue in LDS each
 // level; thread t then sweeps request t, so the waves that do sweep are full, and the result goes
 // back through the same LDS slots to the pixel's home lane.  Requests that need a reflection ray
@@ -30,7 +36,8 @@
 //
 // The recursion of TraceRay (main.cpp:84-188) is unrolled without a stack: the hit chain is traced
 // forward (one combined sweep per segment also settles that segment's shadow rays as a bit mask),
-// then shading runs deepest-first in the reference's operation order.
+// then shading runs deepest-first in the reference's operation order (RT_MODE_EXACT) or is
+// folded in as each segment completes (RT_MODE_FAST, see the kernel's comment).
 #include "rt_device.h"
 #include "rt_math.h"
 
