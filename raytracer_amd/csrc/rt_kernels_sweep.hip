@@ -229,7 +229,7 @@ __device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, co
 // has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r); the line through
 // o = pos + d*0.001 is the line through pos up to the rounding of o (covered by `bound`); and
 // dist(line, g) <= dist(line, c) + |c - g| <= dist(line, c) + R - r, so the bound passes with room
-// to spare: e^2 is 64x the rounding it has to cover, which also absorbs the float evaluation of this
+// to spare: e^2 is 32x the rounding it has to cover, which also absorbs the float evaluation of this
 // test itself.  The records are read with wave-uniform scalar loads; no LDS is involved.
 template <int K>
 __device__ __forceinline__ unsigned long long group_mask(const float4 *heads, int h0, int hn, int n_total, bool lane_on,
