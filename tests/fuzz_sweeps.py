@@ -5,7 +5,9 @@ reference's loop as written) must produce the same bits -- radiance, per-pixel r
 image.  A dropped candidate of the conservative filter or of a bounding-sphere test would show up
 as a differing pixel.
 
-    python tools/fuzz_sweeps.py --scenes 50 --seed 1
+    python tests/fuzz_sweeps.py --scenes 50 --seed 1 [--cpu]
+
+--cpu adds the CPU restatement of the reference (oracle/, test infrastructure) as a fourth opinion.
 
 The transcription kernel is selected per context through the environment, so it runs in a child
 process (this script with --child) that dumps its frames for the parent to compare.
@@ -59,13 +61,18 @@ def random_scene(capi, rng):
     return capi.objects(items), cam, w, h, int(rng.choice([0, 2, 5, 9])), int(rng.choice([1, 4]))
 
 
-def render_all(capi, ctx, seed, n_scenes, sweeps):
+def render_all(capi, ctx, seed, n_scenes, sweeps, with_cpu_checker=False):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n_scenes):
         objs, cam, w, h, depth, spp = random_scene(capi, rng)
         ctx.upload_scene(objs, cam)
         frames = []
+        if with_cpu_checker:       # test infrastructure: the CPU restatement of the reference
+            from oracle import oracle_lib
+            p = capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4)
+            rgb, f32, _ = oracle_lib.render(objs, cam, p, threads=16)
+            frames.append(hashlib.sha256(rgb.tobytes() + f32.tobytes()).hexdigest())
         for sweep in sweeps:
             ctx.render(capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, sweep=sweep))
             frames.append(hashlib.sha256(ctx.download(capi.RT_FMT_RGB8, w, h).tobytes() +
@@ -78,6 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenes", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu", action="store_true", help="also compare with the CPU checker under oracle/ (slow on big scenes)")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     import torch  # noqa: F401  (first, so that one HIP runtime serves the process)
@@ -95,13 +103,14 @@ def main():
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--scenes", str(args.scenes), "--seed", str(args.seed),
                                "--child", path], env=env)
         simple = open(path).read().split()
-    res = render_all(capi, ctx, args.seed, args.scenes, [capi.RT_SWEEP_FLAT, capi.RT_SWEEP_GROUPED])
+    res = render_all(capi, ctx, args.seed, args.scenes, [capi.RT_SWEEP_FLAT, capi.RT_SWEEP_GROUPED], args.cpu)
     bad = 0
     for i, (n, w, h, depth, spp, frames) in enumerate(res):
-        ok = frames[0] == frames[1] == simple[i]
+        ok = all(f == simple[i] for f in frames)
         bad += not ok
         print(f"scene {i}: {n} objects {w}x{h} depth {depth} spp {spp}: {'ok' if ok else 'MISMATCH ' + str([frames[0][:8], frames[1][:8], simple[i][:8]])}", flush=True)
-    print(f"{len(res) - bad}/{len(res)} scenes identical across flat, grouped and transcription kernels")
+    print(f"{len(res) - bad}/{len(res)} scenes identical across flat, grouped and transcription kernels"
+          + (" and the CPU checker" if args.cpu else ""))
     return 1 if bad else 0
 
 
