@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""One-GPU sanity check of the RCCL calls bench.py makes for N > 1 (gather of a band on a side
+stream, all_reduce of the timing vector, barrier) with a process group of one rank: it proves the
+backend, stream and tensor usage on the box; the N > 1 data path itself is covered by the gloo tests
+and by `bench.py --backend gloo`."""
 import os, torch, torch.distributed as dist
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29555", rank=0, world_size=1, device_id=dev)
