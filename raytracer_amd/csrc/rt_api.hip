@@ -102,7 +102,6 @@ static int drain_events(rt_context *ctx, bool block)
 // RT_FMT_RGB8: Bitmap::pData (writebitmap.h:5-17), r,g,b per pixel, rows top-down, no padding.
 // RT_FMT_BMP_BODY: what WriteBitmap emits after its header (writebitmap.h:161-178): rows bottom-up,
 // b,g,r per pixel, each row padded with zeros to a multiple of 4 bytes.
-// One thread produces one output dword (4 consecutive bytes), so stores are coalesced.
 static size_t packed_bytes(const RtFrameDev &fr, int format)
 {
     const size_t w = (size_t)fr.width, rows = (size_t)(fr.row_end - fr.row_begin);
@@ -110,40 +109,51 @@ static size_t packed_bytes(const RtFrameDev &fr, int format)
     return stride * rows;
 }
 
+// One thread = four consecutive pixels of one output row = three output dwords: 16 B read, 12 B written
+// per thread, both contiguous across the wave.  RT_FMT_RGB8 has no row padding, so the whole band is
+// one "row" of width*rows pixels; RT_FMT_BMP_BODY rows are flipped, b,g,r and zero-padded to 4 bytes.
 __global__ __launch_bounds__(256) void pack_rgb24_kernel(const uint32_t *__restrict__ rgba, uint32_t *__restrict__ out,
-                                                         int width, int rows, int bmp_body, unsigned n_dwords)
+                                                         unsigned px_per_row, unsigned n_rows, int bmp_body,
+                                                         unsigned groups_per_row, unsigned dw_per_row)
 {
     const unsigned j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= n_dwords) return;
-    uint32_t word = 0;
-    if (bmp_body) {
-        const unsigned stride_dw = ((unsigned)width * 3u + 3u) >> 2;
-        const unsigned row = j / stride_dw, col = (j - row * stride_dw) * 4u;       // byte column in the padded row
-        const uint32_t *src = rgba + (size_t)(rows - 1 - (int)row) * (size_t)width;  // bottom-up
-#pragma unroll
-        for (unsigned b = 0; b < 4; b++) {
-            const unsigned byte = col + b, px = byte / 3u, ch = byte - px * 3u;
-            if (px < (unsigned)width) word |= ((src[px] >> (8u * (2u - ch))) & 0xffu) << (8u * b);   // b,g,r
-        }
+    const unsigned row = j / groups_per_row, g = j - row * groups_per_row;
+    if (row >= n_rows) return;
+    const unsigned src_row = bmp_body ? n_rows - 1u - row : row;                       // bottom-up
+    const uint32_t *src = rgba + (size_t)src_row * (size_t)px_per_row + 4u * g;
+    const unsigned left = px_per_row - 4u * g;                                         // pixels from here to the row's end
+    uint32_t c[4];
+    if (left >= 4u && ((uintptr_t)src & 15u) == 0) {                                   // one 16-byte load
+        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
     } else {
-        const size_t total = (size_t)width * (size_t)rows;
 #pragma unroll
-        for (unsigned b = 0; b < 4; b++) {
-            const size_t byte = (size_t)j * 4u + b, px = byte / 3u;
-            const unsigned ch = (unsigned)(byte - px * 3u);
-            if (px < total) word |= ((rgba[px] >> (8u * ch)) & 0xffu) << (8u * b);                     // r,g,b
-        }
+        for (unsigned k = 0; k < 4; k++) c[k] = k < left ? src[k] : 0u;
     }
-    out[j] = word;
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+        const uint32_t p = c[k];
+        c[k] = bmp_body ? ((p >> 16) & 0xffu) | (p & 0xff00u) | ((p & 0xffu) << 16)    // b,g,r
+                        : p & 0xffffffu;                                               // r,g,b
+    }
+    const uint32_t w[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
+    uint32_t *dst = out + (size_t)row * (size_t)dw_per_row + 3u * g;
+#pragma unroll
+    for (unsigned k = 0; k < 3; k++)
+        if (3u * g + k < dw_per_row) dst[k] = w[k];
 }
 
 static hipError_t launch_pack(const RtFrameDev &fr, const uint32_t *rgba, uint32_t *out, int format, hipStream_t stream)
 {
-    const size_t n_dwords = (packed_bytes(fr, format) + 3) / 4;
-    if (n_dwords == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((n_dwords + 255) / 256);
-    hipLaunchKernelGGL(pack_rgb24_kernel, dim3(blocks), dim3(256), 0, stream, rgba, out, fr.width,
-                       fr.row_end - fr.row_begin, format == RT_FMT_BMP_BODY ? 1 : 0, (unsigned)n_dwords);
+    const size_t rows = (size_t)(fr.row_end - fr.row_begin), width = (size_t)fr.width;
+    if (rows == 0 || width == 0) return hipSuccess;
+    const bool body = format == RT_FMT_BMP_BODY;
+    const size_t px_per_row = body ? width : width * rows, n_rows = body ? rows : 1;
+    const size_t groups = (px_per_row + 3) / 4, dw_per_row = (px_per_row * 3 + 3) / 4;
+    const size_t threads = groups * n_rows;
+    if (px_per_row > 0xffffffffull || threads > 0xffffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_rgb24_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, rgba, out,
+                       (unsigned)px_per_row, (unsigned)n_rows, body ? 1 : 0, (unsigned)groups, (unsigned)dw_per_row);
     return hipGetLastError();
 }
 
