@@ -81,16 +81,45 @@ def render_all(capi, ctx, seed, n_scenes, sweeps, with_cpu_checker=False):
     return out
 
 
+def check_fast_mode(capi, ctx, seed, n_scenes):
+    """RT_MODE_FAST against RT_MODE_EXACT on the same random scenes: same ray counts, radiance within
+    1e-4 relative, 8-bit within +-1 LSB on >= 99.99 % of the pixels (north_star's tolerance)."""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for i in range(n_scenes):
+        objs, cam, w, h, depth, spp = random_scene(capi, rng)
+        ctx.upload_scene(objs, cam)
+        out = []
+        for mode in (capi.RT_MODE_EXACT, capi.RT_MODE_FAST):
+            ctx.render(capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, mode=mode))
+            out.append((ctx.download(capi.RT_FMT_RGB8, w, h), ctx.download(capi.RT_FMT_F32X4, w, h)))
+        (rgb_e, f_e), (rgb_f, f_f) = out
+        a, b = f_e[..., :3].astype(np.float64), f_f[..., :3].astype(np.float64)
+        fin = np.isfinite(a) & np.isfinite(b)
+        rel = np.max(np.abs(a - b)[fin] / np.maximum(np.abs(a)[fin], 1e-6)) if fin.any() else 0.0
+        same_nan = np.array_equal(np.isfinite(a), np.isfinite(b))
+        lsb = (np.abs(rgb_e.astype(np.int16) - rgb_f.astype(np.int16)).max(axis=-1) <= 1).mean()
+        ok = rel <= 1e-4 and lsb >= 0.9999 and same_nan and np.array_equal(f_e[..., 3], f_f[..., 3])
+        bad += not ok
+        print(f"scene {i}: {len(objs)} objects {w}x{h} depth {depth} spp {spp}: max rel {rel:.2e}, within 1 LSB {lsb:.6f}: "
+              f"{'ok' if ok else 'OUT OF TOLERANCE'}", flush=True)
+    print(f"{n_scenes - bad}/{n_scenes} scenes: fast mode within tolerance of exact mode")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenes", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu", action="store_true", help="also compare with the CPU checker under oracle/ (slow on big scenes)")
+    ap.add_argument("--fast", action="store_true", help="instead: RT_MODE_FAST against RT_MODE_EXACT at the stated tolerance")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     import torch  # noqa: F401  (first, so that one HIP runtime serves the process)
     from raytracer_amd import capi
     ctx = capi.Context(0)
+    if args.fast:
+        return 1 if check_fast_mode(capi, ctx, args.seed, args.scenes) else 0
     if args.child:
         res = render_all(capi, ctx, args.seed, args.scenes, [capi.RT_SWEEP_FLAT])
         with open(args.child, "w") as f:
