@@ -43,6 +43,9 @@ struct rt_context {
     bool have_frame = false;
     int last_outputs = 0;
 
+    void *sample_buf = nullptr;       // sample split: one float4 per (sample, pixel)
+    size_t sample_bytes = 0;
+    int sample_split = 1;             // RT_AMD_SAMPLE_SPLIT=0 turns it off (A/B)
     void *pack_buf = nullptr;         // staging for the 24-bit download formats
     size_t pack_bytes = 0;
     RtStatsDev *stats_dev = nullptr;
@@ -185,6 +188,7 @@ int rt_create(rt_context **out, int device_id)
     ctx->device = device_id;
     const char *kern = getenv("RT_AMD_KERNEL");
     ctx->simple_kernel = kern && strcmp(kern, "simple") == 0;
+    if (const char *sp = getenv("RT_AMD_SAMPLE_SPLIT")) ctx->sample_split = atoi(sp) != 0;
     if (const char *kb = getenv("RT_AMD_LDS_KB")) {       // tuning knob: LDS bytes a workgroup may stage
         int v = atoi(kb);
         if (v >= 8 && v <= 160) ctx->lds_budget = v * 1024;
@@ -212,6 +216,7 @@ void rt_destroy(rt_context *ctx)
         if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
     if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
+    if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -629,6 +634,22 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         fr.chunk = n_pairs < cap ? n_pairs : cap;
     }
 
+    // Sample split: spp waves per tile, their sums resolved in order afterwards.  Worth its buffer
+    // traffic (32 B per sample and pixel) on scenes whose sweeps are long; capped at 1 GiB.
+    const size_t split_bytes = px * (size_t)p->spp * sizeof(float4);
+    if (ctx->sample_split && grouped && px > 0 && split_bytes <= ((size_t)1 << 30) &&
+        rt_sweep_can_split_samples(ctx->scene_grouped, fr, grouped)) {
+        if (ctx->sample_bytes < split_bytes) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->sample_buf) RT_HIP(ctx, hipFree(ctx->sample_buf));
+            ctx->sample_buf = nullptr;
+            ctx->sample_bytes = 0;
+            RT_HIP(ctx, hipMalloc(&ctx->sample_buf, split_bytes));
+            ctx->sample_bytes = split_bytes;
+        }
+        fr.sample_buf = (float4 *)ctx->sample_buf;
+    }
+
     RtSamples smp;
     memset(&smp, 0, sizeof smp);
     memcpy(smp.xy, p->sample_offsets ? p->sample_offsets : kRefPattern, sizeof(float) * 2 * (size_t)p->spp);
@@ -656,6 +677,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
         else RT_HIP(ctx, rt_launch_trace_sweep(grouped ? ctx->scene_grouped : ctx->scene, ctx->cam, fr, smp, sdev,
                                                p->mode == RT_MODE_FAST, grouped, ctx->stream));
+        if (fr.sample_buf) RT_HIP(ctx, rt_launch_resolve_samples(fr, ctx->stream));
     }
     RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     ctx->ev_pending.emplace_back(ev0, ev1);

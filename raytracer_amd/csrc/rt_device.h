@@ -79,6 +79,9 @@ struct RtFrameDev {
     float focal_length;
     int32_t accumulate;   // running mean into f32x4 (raytracer_win/main.cpp:292-314)
     float k1, k2;         // currentSample and 1 / (currentSample + 1)
+    // sample split: one wave per (tile, sample) writes that sample's radiance (w = its ray count) to
+    // sample_buf[s * pixels + pixel]; rt_launch_resolve_samples then adds them up in sample order
+    float4 *sample_buf;
 };
 
 struct RtStatsDev {
@@ -96,6 +99,8 @@ struct RtSamples {
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, bool fast, bool grouped,
                                  hipStream_t stream);
+hipError_t rt_launch_resolve_samples(const RtFrameDev &frame, hipStream_t stream);
+bool rt_sweep_can_split_samples(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped);
 hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);
 

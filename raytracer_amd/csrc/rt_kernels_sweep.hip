@@ -503,6 +503,38 @@ __device__ __forceinline__ V3 add_lights(const RtSceneDev &sc, V3 out, V3 pos, V
     return out;
 }
 
+// main.cpp:210-216 and the options of raytracer_win: scale the sum of the samples, fold it into the
+// running mean when asked to, store the float pixel and its 8-bit quantisation.
+__device__ __forceinline__ void write_pixel(const RtFrameDev &fr, size_t idx, V3 color, float w)
+{
+    color = color * fr.inv_spp;                                              // main.cpp:210
+    if (fr.accumulate) {
+        // raytracer_win/main.cpp:314: bufferVal = ((bufferVal * k1) + vec4(color, 1)) * k2; sample 0
+        // starts from the zero-initialised buffer (:105)
+        const float4 old = fr.k1 == 0.0f ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : fr.f32x4[idx];
+        color = ((v3(old.x, old.y, old.z) * fr.k1) + color) * fr.k2;
+        w = ((old.w * fr.k1) + 1.0f) * fr.k2;
+    }
+    if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, w);
+    if (fr.rgba8) fr.rgba8[idx] = to_u8(color.x) | (to_u8(color.y) << 8) | (to_u8(color.z) << 16) | 0xff000000u;
+}
+
+// Sample split, second half: a pixel's samples were traced by different waves; add them in sample
+// order -- main.cpp:203-209's `color +=` sequence, so the sum is the same float -- and write the pixel.
+__global__ __launch_bounds__(256) void resolve_samples_kernel(RtFrameDev fr, unsigned n_px)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_px) return;
+    V3 color = v3(0.0f, 0.0f, 0.0f);
+    float rays = 0.0f;
+    for (int s = 0; s < fr.spp; s++) {
+        const float4 v = fr.sample_buf[(size_t)s * n_px + i];
+        color = color + v3(v.x, v.y, v.z);                                   // main.cpp:208
+        rays += v.w;                                                         // small integers: exact
+    }
+    write_pixel(fr, i, color, rays);
+}
+
 // COMPACT: pack the live hit points of the workgroup before every bounce sweep (pays off once a
 // sweep is long enough to dwarf three barriers: scenes of more than a few dozen spheres).
 //
@@ -528,7 +560,13 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
     // grouped sweep: nothing is shared between waves (no LDS scene copy, no compaction), so a
     // workgroup is a single wave and a finished tile frees its slot at once
     // (the same goes for scenes of a few spheres, which do not compact: their LDS copy is tiny)
-    const int tile = blockIdx.x * ((GROUPED || (!CHUNKED && !COMPACT)) ? 1 : kWavesPerBlock) + wave;
+    // Sample split (single-wave workgroups only): the unit of work is one sample of one tile, so a
+    // tile whose rays are expensive (grazing rays near the horizon take 12x the average) is spread
+    // over spp waves instead of holding one wave 12x longer than the rest.
+    const bool split = fr.sample_buf != nullptr;
+    const int unit = blockIdx.x * ((GROUPED || (!CHUNKED && !COMPACT)) ? 1 : kWavesPerBlock) + wave;
+    const int tile = split ? unit / fr.spp : unit;
+    const int s_begin = split ? unit - tile * fr.spp : 0, s_end = split ? s_begin + 1 : fr.spp;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x = tx * 8 + (lane & 7);
     const int yr = ty * 8 + (lane >> 3);
@@ -560,7 +598,7 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
     SweepCount cnt = {0u, 0u, 0u};
     V3 color = v3(0.0f, 0.0f, 0.0f);
 
-    for (int s = 0; s < fr.spp; s++) {                                       // main.cpp:203
+    for (int s = s_begin; s < s_end; s++) {                                  // main.cpp:203
         Segment seg;
         bool alive;
         {
@@ -775,19 +813,10 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
     }
 
     if (in_image) {
-        color = color * fr.inv_spp;                                          // main.cpp:210
         const size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
-        float w = (float)(fr.spp + n_refl + n_shadow);
-        if (fr.accumulate) {
-            // raytracer_win/main.cpp:314: bufferVal = ((bufferVal * k1) + vec4(color, 1)) * k2; sample 0
-            // starts from the zero-initialised buffer (:105)
-            const float4 old = fr.k1 == 0.0f ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : fr.f32x4[idx];
-            color = ((v3(old.x, old.y, old.z) * fr.k1) + color) * fr.k2;
-            w = ((old.w * fr.k1) + 1.0f) * fr.k2;
-        }
-        if (fr.f32x4) fr.f32x4[idx] = make_float4(color.x, color.y, color.z, w);
-        if (fr.rgba8)
-            fr.rgba8[idx] = to_u8(color.x) | (to_u8(color.y) << 8) | (to_u8(color.z) << 16) | 0xff000000u;
+        const float rays = (float)((unsigned)(s_end - s_begin) + n_refl + n_shadow);
+        if (split) fr.sample_buf[(size_t)s_begin * ((size_t)fr.width * (size_t)rows) + idx] = make_float4(color.x, color.y, color.z, rays);
+        else write_pixel(fr, idx, color, rays);
     }
 
     if (STATS) {
@@ -811,6 +840,21 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
 
 } // namespace
 
+// The sample split applies to the kernels that run as single-wave workgroups (launcher below).
+bool rt_sweep_can_split_samples(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped)
+{
+    const bool chunked = !grouped && frame.chunk < scene.n_pairs;
+    return frame.spp > 1 && (grouped || (scene.n_pairs < 24 && !chunked));
+}
+
+hipError_t rt_launch_resolve_samples(const RtFrameDev &frame, hipStream_t stream)
+{
+    const size_t n_px = (size_t)frame.width * (size_t)(frame.row_end - frame.row_begin);
+    if (n_px == 0 || n_px > 0xffffffffull) return n_px ? hipErrorInvalidValue : hipSuccess;
+    hipLaunchKernelGGL(resolve_samples_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, frame, (unsigned)n_px);
+    return hipGetLastError();
+}
+
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, bool fast, bool grouped,
                                  hipStream_t stream)
@@ -830,7 +874,9 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     // LDS: flat = pairs | camera table, which the request queue aliases when compacting; grouped = none
     const int second = compact || chunked ? (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4) : 2 * cap;
     const size_t lds_bytes = grouped ? 0 : (size_t)(2 * cap + second) * sizeof(float4);
-    const dim3 grid(one_wave ? tiles : (tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
+    const int units = frame.sample_buf ? tiles * frame.spp : tiles;          // sample split: one wave per (tile, sample)
+    if (frame.sample_buf && !one_wave) return hipErrorInvalidValue;
+    const dim3 grid(one_wave ? units : (tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
 #define RT_LAUNCH_G(C, P, S, L, F, G)                                                                                   \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \

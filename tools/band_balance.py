@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""How well do the cost-balanced row bands balance in time?  Renders each band of an N-way split on
+one GPU and prints the kernel time per band (the slowest band sets the N-GPU frame time).
+
+    python tools/band_balance.py [--gpus 8] [--scene grid1k] [--width 3840 --height 2160 --spp 4]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=8)
+    ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--spp", type=int, default=4)
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    from raytracer_amd import capi, multigpu
+    kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
+    W, H = args.width, args.height
+    objs, cam = capi.make_scene(kind, W, H)
+    ctx = capi.Context(0)
+    ctx.upload_scene(objs, cam)
+    cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
+    for name, bounds in (("cost-balanced", multigpu.plan_bands(cost, H, args.gpus)), ("equal rows", capi.split_bands(H, args.gpus, None))):
+        ms = []
+        for r in range(args.gpus):
+            p = capi.render_params(W, H, args.depth, args.spp, rows=(bounds[r], bounds[r + 1]))
+            ctx.render(p)
+            ctx.render(p)
+            ms.append(ctx.stats()["kernel_ms"])
+        print(f"{name}: bounds {bounds}")
+        print("  ms per band " + " ".join(f"{m:.2f}" for m in ms) + f" | max {max(ms):.2f}, mean {sum(ms) / len(ms):.2f}, "
+              f"max/mean {max(ms) / (sum(ms) / len(ms)):.3f}")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
