@@ -85,8 +85,11 @@ typedef struct rt_camera {
 /* Output planes rt_render fills (bit flags). */
 enum {
     RT_OUT_RGBA8 = 1,   /* 4 B/px: r,g,b as PutPixel would store them (main.cpp:213-216), a = 255 */
-    RT_OUT_F32X4 = 2    /* 16 B/px: radiance after the 1/numSamples scale (main.cpp:210); w = rays
-                           the pixel cost (primary + reflection + shadow): the band cost map  */
+    RT_OUT_F32X4 = 2,   /* 16 B/px: radiance after the 1/numSamples scale (main.cpp:210); w = rays
+                           the pixel cost (primary + reflection + shadow)                       */
+    RT_OUT_COST = 4     /* with RT_OUT_F32X4 and collect_stats: w = the work the pixel's rays took
+                           instead (tests executed, exact tests weighted 32x, 300 per ray) -- the cost map the
+                           row bands are balanced with; the flat sweep of large scenes keeps rays */
 };
 
 /* Download formats. */

@@ -16,7 +16,7 @@ RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_BUFFER_TOO_SMALL = -1, -2, -3, -4
 RT_ERR_NO_SCENE, RT_ERR_NO_FRAME, RT_ERR_LIMIT = -5, -6, -7
 RT_OBJ_SPHERE, RT_OBJ_TILED_PLANE = 0, 1
-RT_OUT_RGBA8, RT_OUT_F32X4 = 1, 2
+RT_OUT_RGBA8, RT_OUT_F32X4, RT_OUT_COST = 1, 2, 4
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
 RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2

@@ -582,8 +582,10 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     if (p->sweep != RT_SWEEP_AUTO && p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown sweep %d", p->sweep);
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
-    if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4))
+    if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4 | RT_OUT_COST))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown output flags 0x%x", outputs);
+    if ((outputs & RT_OUT_COST) && (!(outputs & RT_OUT_F32X4) || !p->collect_stats || p->accumulate))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: RT_OUT_COST needs RT_OUT_F32X4 and collect_stats, and excludes accumulate");
     if (p->accumulate && !(outputs & RT_OUT_F32X4))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: accumulate needs the RT_OUT_F32X4 plane (it holds the running mean)");
     if (p->accumulate && p->accum_index < 0)
@@ -613,6 +615,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     fr.max_depth = p->max_depth;
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
+    fr.cost_w = (outputs & RT_OUT_COST) != 0;
     fr.lens_on = p->lens_offsets != nullptr;
     fr.focal_length = p->focal_length;
     fr.accumulate = p->accumulate != 0;
@@ -684,7 +687,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
 
     ctx->frame = fr;
     ctx->have_frame = true;
-    ctx->last_outputs = outputs;
+    ctx->last_outputs = outputs & (RT_OUT_RGBA8 | RT_OUT_F32X4);
     ctx->stats_pending = p->collect_stats != 0;
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.primary_rays = (uint64_t)px * (uint64_t)p->spp;

@@ -82,6 +82,7 @@ struct RtFrameDev {
     // sample split: one wave per (tile, sample) writes that sample's radiance (w = its ray count) to
     // sample_buf[s * pixels + pixel]; rt_launch_resolve_samples then adds them up in sample order
     float4 *sample_buf;
+    int32_t cost_w;       // stats kernels: f32x4.w = work estimate instead of the ray count (RT_OUT_COST)
 };
 
 struct RtStatsDev {

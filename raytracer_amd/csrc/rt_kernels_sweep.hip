@@ -814,7 +814,12 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
 
     if (in_image) {
         const size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
-        const float rays = (float)((unsigned)(s_end - s_begin) + n_refl + n_shadow);
+        float rays = (float)((unsigned)(s_end - s_begin) + n_refl + n_shadow);
+        // RT_OUT_COST: what the pixel's rays cost instead (this lane did all its sweeps unless the
+        // workgroup compacts its rays, where the counters belong to other pixels)
+        // (tests executed, exact tests at 32 filter tests each, and 300 per ray for its set-up, plane
+        // tests and shading: weights read off the instruction counts of DESIGN.md section 4)
+        if (STATS && !COMPACT && fr.cost_w) rays = (float)cnt.tests + (float)cnt.gtests + 32.0f * (float)cnt.cands + 300.0f * rays;
         if (split) fr.sample_buf[(size_t)s_begin * ((size_t)fr.width * (size_t)rows) + idx] = make_float4(color.x, color.y, color.z, rays);
         else write_pixel(fr, idx, color, rays);
     }

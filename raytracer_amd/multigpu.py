@@ -2,7 +2,8 @@
 
 The reference's only parallel axis is image rows over std::threads (raytracer_cpp/main.cpp:193-196);
 here rows are cut into contiguous bands, one per GPU, balanced by a cost estimate from a
-1/16-resolution pre-pass (the F32X4 plane's w channel = rays traced per pixel).  Every rank runs the
+1/16-resolution pre-pass (the F32X4 plane's w channel with RT_OUT_COST = the tests each pixel's rays
+took, exact tests weighted: rays near the horizon cost an order of magnitude more than the average).  Every rank runs the
 same deterministic pre-pass, so all ranks agree on the bounds without communication.  The only
 exchange step is the gather of the finished bands to rank 0 (RCCL when the tensors are on GPUs, gloo
 on CPU in the tests).
@@ -37,7 +38,7 @@ def prepass_row_cost(ctx, objs, cam, width, height, max_depth, factor=4):
     Leaves the full-size camera uploaded again on return."""
     lw, lh = max(1, -(-width // factor)), max(1, -(-height // factor))
     ctx.upload_scene(objs, scaled_camera(cam, lw, lh))
-    ctx.render(capi.render_params(lw, lh, max_depth, 1, outputs=capi.RT_OUT_F32X4))
+    ctx.render(capi.render_params(lw, lh, max_depth, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True))
     f32 = ctx.download(capi.RT_FMT_F32X4, lw, lh)
     ctx.upload_scene(objs, cam)
     return row_cost_from_prepass(f32[..., 3], height)
