@@ -173,26 +173,64 @@ __device__ __forceinline__ bool nearer(const RtSceneDev &sc, float best, int bes
     return false;
 }
 
+// The reference's test of ray k against both spheres of a pair record (Sphere::Intersects,
+// sceneobjects.h:69-73): glm::intersectRaySphere's
+// dSquared (gtx/intersect.inl:113-116) for the two spheres at once with unfused packed mul/add -- the
+// same IEEE operations in the same order as the scalar code, (xx + yy) + zz for each dot -- then the
+// square root and the distance only for a sphere that passes dSquared <= r*r (:117-122).  A lane far
+// from the origin makes most spheres near its line candidates (the filter's allowance grows with
+// |pos|^2 like the reference's own rounding), so in the grouped sweep, where such lanes set the length
+// of the frame's slowest waves, this path has to be cheap, not just rare.
 template <int K, bool GROUPED>
 __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, const f2 (&q)[K], float bound, float4 A,
                                            float4 B, int slot0)
 {
+    const bool second = GROUPED || slot0 + 1 < sc.n_spheres;    // (padding spheres have -r*r = +FLT_MAX: q is never <= bound)
+    if constexpr (!GROUPED) {
+        // flat sweep: one sphere at a time (measured: the packed form below costs the 6-object scene 7 %
+        // and gains the compacted kernels nothing)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!r.act[k]) continue;
+            float dist;
+            r.cand_run += (q[k].x <= bound ? 1u : 0u) + (q[k].y <= bound ? 1u : 0u);
+            if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) &&
+                nearer<false>(sc, r.best[k], r.slot[k], dist, slot0)) {
+                r.best[k] = dist;
+                r.slot[k] = slot0;
+            }
+            if (q[k].y <= bound && second && sphere_hit(A.y, A.w, B.y, -B.w, r.o[k], r.dn[k], dist) &&
+                nearer<false>(sc, r.best[k], r.slot[k], dist, slot0 + 1)) {
+                r.best[k] = dist;
+                r.slot[k] = slot0 + 1;
+            }
+        }
+        return;
+    }
+    const f2 cx = f2{A.x, A.y}, cy = f2{A.z, A.w}, cz = f2{B.x, B.y};
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if (!r.act[k]) continue;
-        float dist;
-        r.cand_run += (q[k].x <= bound ? 1u : 0u) + (q[k].y <= bound ? 1u : 0u);
-        if (q[k].x <= bound && sphere_hit(A.x, A.z, B.x, -B.z, r.o[k], r.dn[k], dist) &&
-            nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0)) {
-            r.best[k] = dist;
-            r.slot[k] = slot0;
+        const bool c0 = r.act[k] && q[k].x <= bound, c1 = r.act[k] && q[k].y <= bound && second;
+        if (!(c0 || c1)) continue;
+        r.cand_run += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
+        const f2 dx = cx - splat(r.o[k].x), dy = cy - splat(r.o[k].y), dz = cz - splat(r.o[k].z);       // diff = center - rayStarting
+        const f2 t0 = (dx * splat(r.dn[k].x) + dy * splat(r.dn[k].y)) + dz * splat(r.dn[k].z);     // dot(diff, rayNormalizedDirection)
+        const f2 dsq = ((dx * dx + dy * dy) + dz * dz) - t0 * t0;                                   // dot(diff, diff) - t0 * t0
+        if (c0 && !(dsq.x > -B.z)) {
+            const float t1 = sqrtf(-B.z - dsq.x);
+            const float dist = t0.x > t1 + FLT_EPSILON ? t0.x - t1 : t0.x + t1;
+            if (dist > FLT_EPSILON && nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0)) {
+                r.best[k] = dist;
+                r.slot[k] = slot0;
+            }
         }
-        // (padding spheres have -r*r = +FLT_MAX: q is never <= bound for them)
-        if (q[k].y <= bound && (GROUPED || slot0 + 1 < sc.n_spheres) &&
-            sphere_hit(A.y, A.w, B.y, -B.w, r.o[k], r.dn[k], dist) &&
-            nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0 + 1)) {
-            r.best[k] = dist;
-            r.slot[k] = slot0 + 1;
+        if (c1 && !(dsq.y > -B.w)) {
+            const float t1 = sqrtf(-B.w - dsq.y);
+            const float dist = t0.y > t1 + FLT_EPSILON ? t0.y - t1 : t0.y + t1;
+            if (dist > FLT_EPSILON && nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0 + 1)) {
+                r.best[k] = dist;
+                r.slot[k] = slot0 + 1;
+            }
         }
     }
 }
