@@ -445,9 +445,34 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
             return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: object %d has unknown type %d", k, o.type);
         }
         if (emits) {
-            RtEmitterDev e = {o.a[0], o.a[1], o.a[2], k, o.type == RT_OBJ_TILED_PLANE ? 1 : 0, slot, 0, 0};
+            RtEmitterDev e = {o.a[0], o.a[1], o.a[2], k, o.type == RT_OBJ_TILED_PLANE ? 1 : 0, slot, 0, 0};   // order: below
             emit.push_back(e);
         }
+    }
+    // Sweep order of the shadow rays: at most 5 rays share a sweep, and rays towards emitters that lie
+    // in similar directions touch the same groups of spheres, so emitters are ordered along the axis
+    // their positions vary most on (then the next).  Which emitters share a sweep changes no result.
+    {
+        const size_t ne = emit.size();
+        double mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
+        for (const RtEmitterDev &e : emit) { mean[0] += e.cx; mean[1] += e.cy; mean[2] += e.cz; }
+        for (int a = 0; a < 3; a++) mean[a] /= ne ? (double)ne : 1.0;
+        for (const RtEmitterDev &e : emit) {
+            const double c[3] = {e.cx, e.cy, e.cz};
+            for (int a = 0; a < 3; a++) var[a] += (c[a] - mean[a]) * (c[a] - mean[a]);
+        }
+        int ax[3] = {0, 1, 2};
+        std::sort(ax, ax + 3, [&](int a, int b) { return var[a] > var[b]; });
+        std::vector<int32_t> ord(ne);
+        for (size_t i = 0; i < ne; i++) ord[i] = (int32_t)i;
+        auto coord = [&](int32_t i, int a) { return a == 0 ? emit[i].cx : a == 1 ? emit[i].cy : emit[i].cz; };
+        const double split = mean[ax[0]];
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+            const bool sa = coord(a, ax[0]) < split, sb = coord(b, ax[0]) < split;     // two halves along the main axis ...
+            if (sa != sb) return sa;
+            return coord(a, ax[1]) < coord(b, ax[1]);                                  // ... each ordered along the second
+        });
+        for (size_t i = 0; i < ne; i++) emit[i].order = ord[i];
     }
     if (planes.size() > RT_MAX_PLANES)
         return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %zu planes > limit %d", planes.size(), RT_MAX_PLANES);

@@ -50,7 +50,9 @@ struct RtEmitterDev {
     int32_t id;           // list index
     int32_t is_plane;
     int32_t sphere_slot;  // index into geom[] when the emitter is a sphere, else -1
-    int32_t pad0, pad1;
+    int32_t order;        // sweep order: entry i names the emitter whose shadow ray is swept i-th (emitters
+                          // that lie in similar directions share a sweep; light summation stays in list order)
+    int32_t pad1;
 };
 
 struct RtSceneDev {

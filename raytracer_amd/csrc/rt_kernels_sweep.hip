@@ -449,7 +449,7 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, i
     }
 #pragma unroll
     for (int k = kFirst; k < K; k++) {
-        const RtEmitterDev em = sc.emit[e0 + k - kFirst];
+        const RtEmitterDev em = sc.emit[sc.emit[e0 + k - kFirst].order];
         const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);       // GetRayFrom, main.cpp:114
         r.o[k] = pos + edir * 0.001f;                                    // main.cpp:121
         r.d[k] = edir;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, i
         for (int k = kFirst; k < K; k++) {
             // lit iff the nearest object along the shadow ray (lowest index on ties) is the emitter
             // itself and its material at that point is emissive (main.cpp:119-157)
-            const int e = e0 + k - kFirst;
+            const int e = sc.emit[e0 + k - kFirst].order;
             const RtEmitterDev em = sc.emit[e];
             bool is_lit = r.slot[k] != INT_MIN && r.id[k] == em.id;
             if (is_lit && em.is_plane) {
