@@ -663,10 +663,11 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     }
 
     // Sample split: spp waves per tile, their sums resolved in order afterwards.  Worth its buffer
-    // traffic (32 B per sample and pixel) on scenes whose sweeps are long; capped at 1 GiB.
+    // traffic (32 B per sample and pixel) on scenes whose sweeps are long (rt_sweep_can_split_samples);
+    // capped at 1 GiB.
     const size_t split_bytes = px * (size_t)p->spp * sizeof(float4);
-    if (ctx->sample_split && grouped && px > 0 && split_bytes <= ((size_t)1 << 30) &&
-        rt_sweep_can_split_samples(ctx->scene_grouped, fr, grouped)) {
+    if (ctx->sample_split && !ctx->simple_kernel && px > 0 && split_bytes <= ((size_t)1 << 30) &&
+        rt_sweep_can_split_samples(grouped ? ctx->scene_grouped : ctx->scene, fr, grouped)) {
         if (ctx->sample_bytes < split_bytes) {
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->sample_buf) RT_HIP(ctx, hipFree(ctx->sample_buf));

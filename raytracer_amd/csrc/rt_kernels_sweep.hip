@@ -883,11 +883,12 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
 
 } // namespace
 
-// The sample split applies to the kernels that run as single-wave workgroups (launcher below).
+// The sample split pays wherever sweeps are long (grouped sweep: 8-way bands 4.6 -> 2.4 ms; flat sweep
+// of the 1028-sphere scene 33.5 -> 32.2 ms, its four waves then tracing four samples of one tile); on
+// scenes of a few spheres the scratch plane's traffic costs more than the tail it removes.
 bool rt_sweep_can_split_samples(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped)
 {
-    const bool chunked = !grouped && frame.chunk < scene.n_pairs;
-    return frame.spp > 1 && (grouped || (scene.n_pairs < 24 && !chunked));
+    return frame.spp > 1 && (grouped || scene.n_pairs >= 24);
 }
 
 hipError_t rt_launch_resolve_samples(const RtFrameDev &frame, hipStream_t stream)
@@ -918,8 +919,7 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const int second = compact || chunked ? (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4) : 2 * cap;
     const size_t lds_bytes = grouped ? 0 : (size_t)(2 * cap + second) * sizeof(float4);
     const int units = frame.sample_buf ? tiles * frame.spp : tiles;          // sample split: one wave per (tile, sample)
-    if (frame.sample_buf && !one_wave) return hipErrorInvalidValue;
-    const dim3 grid(one_wave ? units : (tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
+    const dim3 grid(one_wave ? units : (units + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
 #define RT_LAUNCH_G(C, P, S, L, F, G)                                                                                   \
     do {                                                                                                            \
         if (lds_bytes > 48 * 1024) {                                                                                \
