@@ -89,3 +89,28 @@ def test_split_bands_properties(capi):
     assert capi.split_bands(0, 2, None) == [0, 0, 0]
     with pytest.raises(capi.RtError):
         capi.split_bands(4, 0, None)
+
+
+def test_ctypes_mirror_matches_the_header(capi, tmp_path):
+    """raytracer_amd/capi.py restates the structs of include/rt_api.h by hand: sizes and field offsets
+    must be what a C compiler makes of the header."""
+    import ctypes as C
+    import subprocess
+    structs = {"rt_material": capi.Material, "rt_object": capi.Object, "rt_camera": capi.Camera,
+               "rt_render_params": capi.RenderParams, "rt_stats": capi.Stats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_api.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
