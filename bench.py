@@ -11,6 +11,12 @@ The sweep is the library default (RT_SWEEP_AUTO: the grouped sweep for this scen
 object prices the FLOPs of the tests that kernel executed; "roofline_flat" is the same frame through
 the flat every-ray-tests-every-sphere sweep, measured in the same run (N = 1).
 
+With N > 1 each rank keeps two frames in flight ("lanes": two contexts, streams and band buffers used
+alternately) so that the gather and assembly of frame k run under the render of frame k + 1; every
+frame is still rendered, gathered and assembled inside the timed region.  N = 1 runs one lane, which
+keeps the per-launch kernel time of the roofline free of overlap (`--lanes 2` there gives ~7 % more
+frames per second by filling one frame's tail with the next frame's waves).
+
 Renders are enqueued on a torch stream (rt_set_stream) so that kernel, gather and assembly order
 on the device without host round trips; the trace kernel's duration is measured per launch with HIP
 events on that stream over the timed region (rt_stats.kernel_ms_total).
@@ -96,6 +102,9 @@ def main():
     ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped"],
                     help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 16 are skipped when "
                          "missed; auto (the library default): grouped from 64 spheres up")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="frames in flight per rank (each lane: its own context, stream and band buffer); 0 = 1 for one "
+                         "GPU, 2 for N > 1 so that the gather of frame k runs under the render of frame k + 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
@@ -161,40 +170,66 @@ def main():
     grouped = st["group_tests_run"] > 0
 
     params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=sweep)
-    stream = torch.cuda.Stream(device=dev)
-    ctx.set_stream(stream.cuda_stream)
+
+    # Lanes: frames in flight on this rank.  A lane owns a context (a context's renders share scratch and
+    # must follow one another on one stream), a stream, a band buffer and, on rank 0, a frame.  With two
+    # lanes the gather and assembly of frame k overlap the render of frame k + 1; the collectives are
+    # still issued in the same order on every rank.
+    n_lanes = args.lanes if args.lanes > 0 else (2 if world > 1 else 1)
+    lanes = []
+    for i in range(n_lanes):
+        c = ctx
+        b, f = band, frame
+        if i > 0:
+            c = capi.Context(local)
+            c.upload_scene(objs, cam)
+            b = torch.zeros_like(band)
+            c.bind_framebuffer(capi.RT_OUT_RGBA8, b.data_ptr(), b.numel() * 4)
+            f = torch.zeros_like(frame) if rank == 0 else None
+            c.render(params)                                # untimed: the lane has rendered once (stats, scratch)
+        s_ = torch.cuda.Stream(device=dev)
+        c.set_stream(s_.cuda_stream)
+        lanes.append((c, s_, b, f))
+    issued = [0]
 
     def step():
+        c, stream, b, f = lanes[issued[0] % n_lanes]
+        issued[0] += 1
         with torch.cuda.stream(stream):
-            ctx.render(params, wait=False)                  # enqueue only
+            c.render(params, wait=False)                    # enqueue only
             if world == 1:
-                frame.copy_(band, non_blocking=True)        # the N = 1 "assembly"
+                f.copy_(b, non_blocking=True)               # the N = 1 "assembly"
             if world > 1 and not rehearsal:
-                multigpu.gather_bands(band, bounds, rank, world, out=frame)
+                multigpu.gather_bands(b, bounds, rank, world, out=f)
         if world > 1 and rehearsal:
             stream.synchronize()
-            host = multigpu.gather_bands(band.cpu(), bounds, rank, world)
+            host = multigpu.gather_bands(b.cpu(), bounds, rank, world)
             if rank == 0:
-                frame.copy_(host)
+                f.copy_(host)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def lane_stats():
+        sts = [c.stats() for c, _, _, _ in lanes]
+        return sum(x["kernels_timed"] for x in sts), sum(x["kernel_ms_total"] for x in sts)
+
     for _ in range(args.warmup):
         step()
     fence()
-    before = ctx.stats()
+    before = lane_stats()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    after = ctx.stats()
-    assert after["kernels_timed"] - before["kernels_timed"] == args.steps
-    kernel_ms = after["kernel_ms_total"] - before["kernel_ms_total"]
+    after = lane_stats()
+    assert after[0] - before[0] == args.steps
+    kernel_ms = after[1] - before[1]
+    frame = lanes[(issued[0] - 1) % n_lanes][3]             # the last frame assembled
 
     tot = torch.tensor([elapsed, float(my_rays), float(my_flop), kernel_ms / max(1, args.steps)],
                        dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -228,6 +263,7 @@ def main():
                        "rays_per_frame": int(rays), "bands": bounds,
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                                                                          "sphere_tests", "sphere_tests_run", "group_tests_run", "exact_tests_run")},
+                       "lanes": n_lanes,
                        "parallelism": f"row-bands x{world}" + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
@@ -236,6 +272,8 @@ def main():
                          "algorithmic_flop_per_launch": int(my_flop),
                          "kernel": "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)",
                          "brute_force_equivalent_tflops": (brute_flop / (k0_ms * 1e-3)) / 1e12 if k0_ms > 0 else 0.0,
+                         "lanes_note": None if n_lanes == 1 else "kernel_ms is per launch with %d frames in flight: launches overlap on "
+                                       "the device, so it overstates the time a launch would take alone" % n_lanes,
                          "note": "15 FLOP x (ray,sphere) and (ray,group) tests EXECUTED + 5 FLOP x rays x planes; for the "
                                  "flat sweep that equals SURVEY 8d's 15 x rays x spheres; brute_force_equivalent = that "
                                  "count over this kernel's time; HBM traffic is the framebuffer only (4 B/px)"},
@@ -265,8 +303,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(capi, W, H, args.depth, args.spp, kind, offsets)
         print(json.dumps(out), flush=True)
 
-    ctx.set_stream(0)
-    ctx.close()
+    for c, _, _, _ in lanes:
+        c.set_stream(0)
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
