@@ -248,6 +248,14 @@ int rt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t 
  * the complete file. */
 int rt_bmp_header(int32_t width, int32_t height, uint8_t out[54]);
 
+/* Introspection, host only (no device needed): the grouping rt_upload_scene builds for
+ * RT_SWEEP_GROUPED.  No counterpart in the reference.  group_bounds / super_bounds receive 4 floats per
+ * group / super-group (centre, radius of the bounding sphere); group_of_object receives, per object,
+ * the index of its group or -1 for a plane; super-group s holds groups [8s, 8s + 8).  Returns
+ * RT_ERR_BUFFER_TOO_SMALL (with the counts filled in) when max_groups is too small. */
+int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t *n_groups, int32_t *n_supers,
+                   float *group_bounds, float *super_bounds, int32_t *group_of_object);
+
 #ifdef __cplusplus
 }
 #endif

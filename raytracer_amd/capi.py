@@ -61,7 +61,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
+    "rt_create", "rt_destroy", "rt_plan_groups", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
     "rt_pack_framebuffer", "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
     "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
     "rt_make_scene", "rt_split_bands", "rt_write_bmp", "rt_bmp_header",
@@ -80,6 +80,8 @@ def _load():
     lib.rt_destroy.restype = None
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Object), i32, C.POINTER(Camera)]
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.rt_plan_groups.argtypes = [C.POINTER(Object), i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.POINTER(i32)]
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_sync.argtypes = [vp]
@@ -316,6 +318,21 @@ def tiled_plane(origin, normal, white=None, black=None):
     o.mat = white if white is not None else material((1, 1, 1), (1, 1, 1), 0.6)
     o.mat2 = black if black is not None else material((0, 0, 0), (0, 0, 0), 0.6)
     return o
+
+
+def plan_groups(objs):
+    """rt_plan_groups: (group bounds [G,4], super-group bounds [S,4], group index per object [n])."""
+    n = len(objs)
+    cap = n // 1 + 1
+    ng, ns = C.c_int32(0), C.c_int32(0)
+    gb = np.zeros((cap, 4), dtype=np.float32)
+    sb = np.zeros((cap, 4), dtype=np.float32)
+    of = np.zeros(n, dtype=np.int32)
+    rc = lib.rt_plan_groups(objs, n, cap, C.byref(ng), C.byref(ns), gb.ctypes.data_as(C.POINTER(C.c_float)),
+                            sb.ctypes.data_as(C.POINTER(C.c_float)), of.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise RtError(rc, lib.rt_last_error(None).decode())
+    return gb[:ng.value], sb[:ns.value], of
 
 
 def load_scene_file(path, width, height):

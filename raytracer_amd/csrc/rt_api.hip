@@ -555,6 +555,42 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     return RT_OK;
 }
 
+int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t *n_groups, int32_t *n_supers,
+                   float *group_bounds, float *super_bounds, int32_t *group_of_object)
+{
+    if (!objs || n <= 0 || !n_groups || !n_supers) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_plan_groups: NULL argument or n <= 0");
+    std::vector<float4> geom;
+    std::vector<float> radius;
+    std::vector<int32_t> sph_id;
+    for (int32_t k = 0; k < n; k++) {
+        if (group_of_object) group_of_object[k] = -1;
+        if (objs[k].type != RT_OBJ_SPHERE) continue;
+        geom.push_back(make_float4(objs[k].a[0], objs[k].a[1], objs[k].a[2], objs[k].radius * objs[k].radius));
+        radius.push_back(objs[k].radius);
+        sph_id.push_back(k);
+    }
+    GroupedScene grp;
+    build_groups(geom, radius, sph_id, grp);
+    *n_groups = grp.n_groups;
+    *n_supers = grp.n_supers;
+    if (grp.n_groups > max_groups)
+        return fail(nullptr, RT_ERR_BUFFER_TOO_SMALL, "rt_plan_groups: %d groups, room for %d", grp.n_groups, max_groups);
+    auto unpack = [](const std::vector<float4> &rec, int count, float *dst) {
+        for (int g = 0; dst && g < count; g++) {
+            const float4 A = rec[2 * (g >> 1)], B = rec[2 * (g >> 1) + 1];
+            dst[4 * g + 0] = (g & 1) ? A.y : A.x;
+            dst[4 * g + 1] = (g & 1) ? A.w : A.z;
+            dst[4 * g + 2] = (g & 1) ? B.y : B.x;
+            dst[4 * g + 3] = (g & 1) ? B.w : B.z;
+        }
+    };
+    unpack(grp.heads, grp.n_groups, group_bounds);
+    unpack(grp.supers, grp.n_supers, super_bounds);
+    for (size_t i = 0; group_of_object && i < sph_id.size(); i++)
+        group_of_object[sph_id[i]] = grp.slot_of[i] / (2 * RT_GROUP_PAIRS);
+    return RT_OK;
+}
+
 int rt_set_camera(rt_context *ctx, const rt_camera *cam)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;

@@ -114,3 +114,48 @@ def test_ctypes_mirror_matches_the_header(capi, tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def _grouping_invariants(capi, objs):
+    gb, sb, of = capi.plan_groups(objs)
+    gb64, sb64 = gb.astype(np.float64), sb.astype(np.float64)
+    sph = [k for k, o in enumerate(objs) if o.type == capi.RT_OBJ_SPHERE]
+    assert all(of[k] == -1 for k in range(len(objs)) if k not in set(sph))
+    counts = np.bincount(of[sph], minlength=len(gb))
+    assert counts.min() >= 1 and counts.max() <= 16 and len(sb) == (len(gb) + 7) // 8
+    for k in sph:                        # every sphere lies inside its group's bounding sphere ...
+        o, g = objs[k], of[k]
+        c, r = np.array(list(o.a), dtype=np.float64), abs(float(o.radius))
+        if not (np.isfinite(c).all() and np.isfinite(r)):
+            assert counts[g] == 1        # a sphere nothing can hit sits in a group of its own
+            continue
+        assert np.linalg.norm(c - gb64[g, :3]) + r <= gb64[g, 3] * (1 + 1e-6) or np.isinf(gb64[g, 3])
+    for g in range(len(gb)):             # ... and every group inside its super-group's
+        s = g // 8
+        if np.isfinite(gb64[g]).all() and np.isfinite(sb64[s]).all():
+            assert np.linalg.norm(gb64[g, :3] - sb64[s, :3]) + gb64[g, 3] <= sb64[s, 3] * (1 + 1e-6)
+    return gb, sb, of
+
+
+def test_grouping_invariants(capi):
+    """rt_plan_groups (the grouping behind RT_SWEEP_GROUPED, host only): every sphere in exactly one
+    group of at most 16, bounds that contain their members at both levels, outliers and unhittable
+    spheres on their own, planes in no group; and the grouping actually is local."""
+    objs, _ = capi.make_scene(capi.RT_SCENE_GRID1K, 64, 64)
+    gb, sb, of = _grouping_invariants(capi, objs)
+    assert 65 <= len(gb) <= 80 and np.median(gb[:, 3]) < 6.0      # 4x4 blocks of a 1.5-pitch grid; the 4 lights apart
+    lights = [k for k, o in enumerate(objs) if any(o.mat.emissive)]
+    assert len(lights) == 4 and all(np.count_nonzero(of == of[k]) <= 2 for k in lights)
+    objs16, _ = capi.make_scene(capi.RT_SCENE_GRID16K, 64, 64)
+    gb16, _, _ = _grouping_invariants(capi, objs16)
+    assert len(gb16) < 1200
+    rng = np.random.default_rng(9)
+    M, S, P = capi.material, capi.sphere, capi.tiled_plane
+    m = M((.5, .5, .5), (.5, .5, .5), 0.2)
+    odd = [S(m, tuple(rng.normal(0, 5, 3)), float(rng.uniform(.1, 1))) for _ in range(333)]
+    odd += [S(m, (1e6, 0, 0), 5e5), S(m, (float("nan"), 0, 0), 1.0), S(m, (0, 0, 0), float("inf")), P((0, 0, 0), (0, 1, 0)),
+            S(m, (0, 1, 0), 1.0)] + [S(m, (2, 2, 2), 1.0) for _ in range(40)]
+    _grouping_invariants(capi, capi.objects(odd))
+    one = capi.objects([P((0, 0, 0), (0, 1, 0))])
+    gb0, sb0, of0 = capi.plan_groups(one)
+    assert len(gb0) == 0 and len(sb0) == 0 and list(of0) == [-1]
