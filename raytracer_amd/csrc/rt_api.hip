@@ -698,12 +698,23 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         fr.chunk = n_pairs < cap ? n_pairs : cap;
     }
 
-    // Sample split: spp waves per tile, their sums resolved in order afterwards.  Worth its buffer
+    // One sample per lane where the kernel allows it (see the kernel's comment) ...
+    fr.tile_w = fr.tile_h = 8;
+    const RtSceneDev &use_scene = grouped ? ctx->scene_grouped : ctx->scene;
+    if (ctx->sample_split && !ctx->simple_kernel && rt_sweep_can_put_samples_in_lanes(use_scene, fr, grouped)) {
+        static const int kTile[7][2] = {{8, 8}, {8, 4}, {4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};   // spp 1, 2, 4 ... 64
+        int lg = 0;
+        while ((1 << lg) < p->spp) lg++;
+        fr.lane_samples = p->spp;
+        fr.tile_w = kTile[lg][0];
+        fr.tile_h = kTile[lg][1];
+    }
+    // ... else the sample split: spp waves per tile, their sums resolved in order afterwards.  Worth its buffer
     // traffic (32 B per sample and pixel) on scenes whose sweeps are long (rt_sweep_can_split_samples);
     // capped at 1 GiB.
     const size_t split_bytes = px * (size_t)p->spp * sizeof(float4);
-    if (ctx->sample_split && !ctx->simple_kernel && px > 0 && split_bytes <= ((size_t)1 << 30) &&
-        rt_sweep_can_split_samples(grouped ? ctx->scene_grouped : ctx->scene, fr, grouped)) {
+    if (ctx->sample_split && !fr.lane_samples && !ctx->simple_kernel && px > 0 && split_bytes <= ((size_t)1 << 30) &&
+        rt_sweep_can_split_samples(use_scene, fr, grouped)) {
         if (ctx->sample_bytes < split_bytes) {
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->sample_buf) RT_HIP(ctx, hipFree(ctx->sample_buf));

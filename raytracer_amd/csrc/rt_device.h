@@ -84,6 +84,10 @@ struct RtFrameDev {
     // sample split: one wave per (tile, sample) writes that sample's radiance (w = its ray count) to
     // sample_buf[s * pixels + pixel]; rt_launch_resolve_samples then adds them up in sample order
     float4 *sample_buf;
+    // samples in lanes (single-wave kernels, spp a power of two <= 64): a wave covers 64/spp pixels, one
+    // lane per (pixel, sample); the samples of a pixel are summed in order across lanes.  tile_w x tile_h
+    // is the pixel footprint (8x8 when off).
+    int32_t lane_samples, tile_w, tile_h;
     int32_t cost_w;       // stats kernels: f32x4.w = work estimate instead of the ray count (RT_OUT_COST)
 };
 
@@ -103,6 +107,7 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
                                  const RtSamples &samples, RtStatsDev *stats, bool fast, bool grouped,
                                  hipStream_t stream);
 hipError_t rt_launch_resolve_samples(const RtFrameDev &frame, hipStream_t stream);
+bool rt_sweep_can_put_samples_in_lanes(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped);
 bool rt_sweep_can_split_samples(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped);
 hipError_t rt_launch_trace_exact(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
                                  const RtSamples &samples, RtStatsDev *stats, hipStream_t stream);

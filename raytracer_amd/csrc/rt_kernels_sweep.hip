@@ -592,22 +592,31 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int tiles_x = (fr.width + 7) >> 3;
     const int rows = fr.row_end - fr.row_begin;
-    const int tiles_y = (rows + 7) >> 3;
+    const int tiles_x = (fr.width + fr.tile_w - 1) / fr.tile_w;
+    const int tiles_y = (rows + fr.tile_h - 1) / fr.tile_h;
     // grouped sweep: nothing is shared between waves (no LDS scene copy, no compaction), so a
     // workgroup is a single wave and a finished tile frees its slot at once
     // (the same goes for scenes of a few spheres, which do not compact: their LDS copy is tiny)
-    // Sample split (single-wave workgroups only): the unit of work is one sample of one tile, so a
-    // tile whose rays are expensive (grazing rays near the horizon take 12x the average) is spread
-    // over spp waves instead of holding one wave 12x longer than the rest.
+    //
+    // Two ways to give a wave one sample per lane instead of a loop over samples (a tile whose rays are
+    // expensive -- grazing rays near the horizon take 12x the average -- then holds its waves a
+    // fraction as long):
+    //  * samples in lanes (single-wave kernels, spp a power of two): the wave covers 64/spp pixels
+    //    (4x4 at 4 spp), lane = pixel * spp + sample; the samples of a pixel are added up in sample
+    //    order across lanes at the end.  The smaller footprint also narrows the set of groups a wave
+    //    has to visit, and the samples of a pixel end their paths together.
+    //  * sample split (otherwise): spp waves per 8x8 tile, each writes its sample's radiance to a
+    //    scratch plane that resolve_samples_kernel adds up in sample order.
+    const int ls = fr.lane_samples;                                          // 0 or spp
     const bool split = fr.sample_buf != nullptr;
     const int unit = blockIdx.x * ((GROUPED || (!CHUNKED && !COMPACT)) ? 1 : kWavesPerBlock) + wave;
     const int tile = split ? unit / fr.spp : unit;
-    const int s_begin = split ? unit - tile * fr.spp : 0, s_end = split ? s_begin + 1 : fr.spp;
+    const int lane_sample = ls ? lane & (ls - 1) : 0, lane_pixel = ls ? lane / ls : lane;
+    const int s_begin = split ? unit - tile * fr.spp : lane_sample, s_end = (split || ls) ? s_begin + 1 : fr.spp;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = tx * 8 + (lane & 7);
-    const int yr = ty * 8 + (lane >> 3);
+    const int x = tx * fr.tile_w + lane_pixel % fr.tile_w;
+    const int yr = ty * fr.tile_h + lane_pixel / fr.tile_w;
     const int y = fr.row_begin + yr;
     const bool in_image = (tile < tiles_x * tiles_y) && x < fr.width && yr < rows;
 
@@ -850,7 +859,7 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
         if (in_image) color = color + child;                                 // main.cpp:208
     }
 
-    if (in_image) {
+    {
         const size_t idx = (size_t)yr * (size_t)fr.width + (size_t)x;
         float rays = (float)((unsigned)(s_end - s_begin) + n_refl + n_shadow);
         // RT_OUT_COST: what the pixel's rays cost instead (this lane did all its sweeps unless the
@@ -858,8 +867,20 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
         // (tests executed, exact tests at 32 filter tests each, and 300 per ray for its set-up, plane
         // tests and shading: weights read off the instruction counts of DESIGN.md section 4)
         if (STATS && !COMPACT && fr.cost_w) rays = (float)cnt.tests + (float)cnt.gtests + 32.0f * (float)cnt.cands + 300.0f * rays;
-        if (split) fr.sample_buf[(size_t)s_begin * ((size_t)fr.width * (size_t)rows) + idx] = make_float4(color.x, color.y, color.z, rays);
-        else write_pixel(fr, idx, color, rays);
+        if (ls) {
+            // samples in lanes: main.cpp:203-209's `color +=` over the pixel's lanes, in sample order
+            const int base = lane - lane_sample;
+            V3 sum = v3(0.0f, 0.0f, 0.0f);
+            float all_rays = 0.0f;
+            for (int t = 0; t < ls; t++) {
+                sum = sum + v3(__shfl(color.x, base + t, 64), __shfl(color.y, base + t, 64), __shfl(color.z, base + t, 64));
+                all_rays += __shfl(rays, base + t, 64);
+            }
+            if (in_image && lane_sample == 0) write_pixel(fr, idx, sum, all_rays);
+        } else if (in_image) {
+            if (split) fr.sample_buf[(size_t)s_begin * ((size_t)fr.width * (size_t)rows) + idx] = make_float4(color.x, color.y, color.z, rays);
+            else write_pixel(fr, idx, color, rays);
+        }
     }
 
     if (STATS) {
@@ -886,6 +907,15 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
 // The sample split pays wherever sweeps are long (grouped sweep: 8-way bands 4.6 -> 2.4 ms; flat sweep
 // of the 1028-sphere scene 33.5 -> 32.2 ms, its four waves then tracing four samples of one tile); on
 // scenes of a few spheres the scratch plane's traffic costs more than the tail it removes.
+// Samples in lanes: the grouped sweep (single-wave workgroups), when spp is a power of two that fits a
+// wave.  (Measured: grid-1024 4K 4 spp 12.05 ms against 12.6-13.0 with the sample split and 13.3 with a
+// loop over samples; the flat sweep of the 6-object scene loses 10-20 % to it, so it keeps its loop.)
+bool rt_sweep_can_put_samples_in_lanes(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped)
+{
+    (void)scene;
+    return grouped && frame.spp > 1 && frame.spp <= 64 && (frame.spp & (frame.spp - 1)) == 0;
+}
+
 bool rt_sweep_can_split_samples(const RtSceneDev &scene, const RtFrameDev &frame, bool grouped)
 {
     return frame.spp > 1 && (grouped || scene.n_pairs >= 24);
@@ -904,7 +934,7 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
                                  hipStream_t stream)
 {
     const int rows = frame.row_end - frame.row_begin;
-    const int tiles = ((frame.width + 7) / 8) * ((rows + 7) / 8);
+    const int tiles = ((frame.width + frame.tile_w - 1) / frame.tile_w) * ((rows + frame.tile_h - 1) / frame.tile_h);
     if (tiles <= 0) return hipSuccess;
     const int n_pairs = scene.n_pairs;
     const bool chunked = !grouped && frame.chunk < n_pairs;
