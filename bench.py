@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped"],
-                    help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 16 are skipped when "
+                    help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 8 are skipped when "
                          "missed; auto (the library default): grouped from 64 spheres up")
     ap.add_argument("--lanes", type=int, default=0,
                     help="frames in flight per rank (each lane: its own context, stream and band buffer); 0 = 1 for one "

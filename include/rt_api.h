@@ -115,7 +115,7 @@ enum {
     RT_SWEEP_AUTO = 0,   /* grouped for scenes of 64 spheres or more, flat below                    */
     RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */
-    RT_SWEEP_GROUPED = 2 /* spheres are grouped at upload (16 per group along a Morton curve, 8
+    RT_SWEEP_GROUPED = 2 /* spheres are grouped at upload (8 per group along a Morton curve, 8
                             groups per super-group); a wave skips a group when the lines of all its
                             rays miss the group's bounding sphere.  Scenes of fewer than 64 spheres
                             take the flat sweep regardless                                         */

@@ -13,13 +13,13 @@
 //   emit   RtEmitterDev[n_emit] objects with a non-zero emissive material, in list order
 //
 // Grouped layout (RT_SWEEP_GROUPED): a second copy of pairs/sph_id in which the spheres are sorted
-// along a Morton curve and cut into GROUPS of at most 16 (8 pair records each, short groups padded
+// along a Morton curve and cut into GROUPS of at most 8 (4 pair records each, short groups padded
 // with unhittable spheres), plus
 //   heads  float4[2*ceil(n_groups/2)]  bounding spheres of the groups, two per 32-byte record:
 //                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail has R = -1: never passes)
 //   supers float4[2*ceil(n_supers/2)]  the same one level up: bounding spheres of RT_SUPER_GROUPS
 //                              consecutive groups
-// A ray whose LINE misses a group's bounding sphere skips the group's 16 spheres.  The grouped
+// A ray whose LINE misses a group's bounding sphere skips the group's 8 spheres.  The grouped
 // arrays are read with wave-uniform scalar loads straight from HBM/L2: no LDS staging, no size limit.  Slot order is
 // no longer list order there, so distance ties are broken by sph_id explicitly.
 #ifndef RT_DEVICE_H
@@ -34,8 +34,8 @@
 #define RT_MAX_SPP 64
 #define RT_MAX_PLANES 16
 #define RT_MAX_EMITTERS 64
-#define RT_GROUP_PAIRS 8      // pair records per group (16 spheres)
-#define RT_SUPER_GROUPS 8      // groups per super-group (128 spheres)
+#define RT_GROUP_PAIRS 4      // pair records per group (8 spheres)
+#define RT_SUPER_GROUPS 8      // groups per super-group (64 spheres)
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {

@@ -7,7 +7,7 @@
 //   FLAT     every ray against every sphere.  A 256-thread workgroup = four tiles sharing ONE LDS
 //            copy of the list (broadcast ds_read_b128 x2 per pair), streamed in chunks when it
 //            does not fit; scenes of a few spheres run as single-wave workgroups.
-//   GROUPED  groups of 16 spheres under two levels of bounding spheres; a wave visits a group only
+//   GROUPED  groups of 8 spheres under two levels of bounding spheres; a wave visits a group only
 //            if the line of one of its rays can touch the bound.  Records come through wave-uniform
 //            scalar loads, workgroups are single waves, no LDS (see group_mask()).
 // Both give the same bits.

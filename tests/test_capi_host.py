@@ -122,7 +122,7 @@ def _grouping_invariants(capi, objs):
     sph = [k for k, o in enumerate(objs) if o.type == capi.RT_OBJ_SPHERE]
     assert all(of[k] == -1 for k in range(len(objs)) if k not in set(sph))
     counts = np.bincount(of[sph], minlength=len(gb))
-    assert counts.min() >= 1 and counts.max() <= 16 and len(sb) == (len(gb) + 7) // 8
+    assert counts.min() >= 1 and counts.max() <= 8 and len(sb) == (len(gb) + 7) // 8
     for k in sph:                        # every sphere lies inside its group's bounding sphere ...
         o, g = objs[k], of[k]
         c, r = np.array(list(o.a), dtype=np.float64), abs(float(o.radius))
@@ -139,16 +139,16 @@ def _grouping_invariants(capi, objs):
 
 def test_grouping_invariants(capi):
     """rt_plan_groups (the grouping behind RT_SWEEP_GROUPED, host only): every sphere in exactly one
-    group of at most 16, bounds that contain their members at both levels, outliers and unhittable
+    group of at most 8, bounds that contain their members at both levels, outliers and unhittable
     spheres on their own, planes in no group; and the grouping actually is local."""
     objs, _ = capi.make_scene(capi.RT_SCENE_GRID1K, 64, 64)
     gb, sb, of = _grouping_invariants(capi, objs)
-    assert 65 <= len(gb) <= 80 and np.median(gb[:, 3]) < 6.0      # 4x4 blocks of a 1.5-pitch grid; the 4 lights apart
+    assert 129 <= len(gb) <= 160 and np.median(gb[:, 3]) < 4.5    # 2x4 blocks of a 1.5-pitch grid; the 4 lights apart
     lights = [k for k, o in enumerate(objs) if any(o.mat.emissive)]
     assert len(lights) == 4 and all(np.count_nonzero(of == of[k]) <= 2 for k in lights)
     objs16, _ = capi.make_scene(capi.RT_SCENE_GRID16K, 64, 64)
     gb16, _, _ = _grouping_invariants(capi, objs16)
-    assert len(gb16) < 1200
+    assert len(gb16) < 2400
     rng = np.random.default_rng(9)
     M, S, P = capi.material, capi.sphere, capi.tiled_plane
     m = M((.5, .5, .5), (.5, .5, .5), 0.2)
