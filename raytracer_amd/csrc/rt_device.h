@@ -19,7 +19,7 @@
 //                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail has R = -1: never passes)
 //   supers float4[2*ceil(n_supers/2)]  the same one level up: bounding spheres of RT_SUPER_GROUPS
 //                              consecutive groups
-// A ray whose LINE misses a group's bounding sphere skips the group's 8 spheres.  The grouped
+// A ray that passes a group's bounding sphere at a distance skips the group's 8 spheres.  The grouped
 // arrays are read with wave-uniform scalar loads straight from HBM/L2: no LDS staging, no size limit.  Slot order is
 // no longer list order there, so distance ties are broken by sph_id explicitly.
 #ifndef RT_DEVICE_H

@@ -262,11 +262,13 @@ __device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, co
 
 // Grouped sweep: which of the bounding spheres [2*h0, 2*h0 + 2*hn) of `heads` can any ray of this
 // WAVE touch?  (Group heads, or the super-group heads one level up: same record, same test.)
-// A bounding sphere (centre g, radius R) is skipped when every ray's line passes it at more than
-// R + e, with e^2 = bound + 2^-14 (|g - pos|^2 + R^2).  Soundness: a sphere the reference accepts
-// has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r); the line through
-// o = pos + d*0.001 is the line through pos up to the rounding of o (covered by `bound`); and
-// dist(line, g) <= dist(line, c) + |c - g| <= dist(line, c) + R - r, so the bound passes with room
+// A bounding sphere (centre g, radius R) is skipped when every ray {pos + t d, t >= 0} passes it at
+// more than R + e, with e^2 = bound + 2^-14 (|g - pos|^2 + R^2).  Soundness: a sphere the reference
+// accepts has true line distance^2 <= r^2 + 2^-20 |c - o|^2 (its float dSquared <= r*r) and its hit
+// lies ahead of o (distance > FLT_EPSILON, gtx/intersect.inl:121-122), i.e. on the ray from o, a point
+// of which is within r of c; the ray from
+// o = pos + d*0.001 is part of the ray from pos up to the rounding of o (covered by `bound`); and
+// dist(ray, g) <= dist(ray, c) + |c - g| <= dist(ray, c) + R - r, so the bound passes with room
 // to spare: e^2 is 32x the rounding it has to cover, which also absorbs the float evaluation of this
 // test itself.  The records are read with wave-uniform scalar loads; no LDS is involved.
 template <int K>
@@ -290,8 +292,10 @@ __device__ __forceinline__ unsigned long long group_mask(const float4 *heads, in
         for (int k = 0; k < K; k++) q[k] = pk_fma(uy, dy[k], q[k]);
 #pragma unroll
         for (int k = 0; k < K; k++) q[k] = pk_fma(uz, dz[k], q[k]);
+        // the RAY, not its line: a centre behind the origin (s = u.d < 0) is |u| away from the ray, so
+        // q = w - max(s, 0) * s (written so that a NaN s still gives a NaN q and keeps the group)
 #pragma unroll
-        for (int k = 0; k < K; k++) q[k] = pk_fma(-q[k], q[k], w);
+        for (int k = 0; k < K; k++) q[k] = pk_fma(-f2{fmaxf(q[k].x, 0.0f), fmaxf(q[k].y, 0.0f)}, q[k], w);
         float m0 = q[0].x, m1 = q[0].y;
 #pragma unroll
         for (int k = 1; k < K; k++) { m0 = fminf(m0, q[k].x); m1 = fminf(m1, q[k].y); }
