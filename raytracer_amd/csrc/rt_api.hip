@@ -445,7 +445,8 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
             return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: object %d has unknown type %d", k, o.type);
         }
         if (emits) {
-            RtEmitterDev e = {o.a[0], o.a[1], o.a[2], k, o.type == RT_OBJ_TILED_PLANE ? 1 : 0, slot, 0, 0};   // order: below
+            RtEmitterDev e = {o.a[0], o.a[1], o.a[2], k, o.type == RT_OBJ_TILED_PLANE ? 1 : 0, slot, 0,
+                              o.type == RT_OBJ_TILED_PLANE ? INFINITY : fabsf(o.radius)};   // order: below
             emit.push_back(e);
         }
     }

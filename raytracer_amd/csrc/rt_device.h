@@ -52,7 +52,7 @@ struct RtEmitterDev {
     int32_t sphere_slot;  // index into geom[] when the emitter is a sphere, else -1
     int32_t order;        // sweep order: entry i names the emitter whose shadow ray is swept i-th (emitters
                           // that lie in similar directions share a sweep; light summation stays in list order)
-    int32_t pad1;
+    float radius;         // |radius| of a sphere emitter, +inf for a plane (grouped sweep: decided shadow rays)
 };
 
 struct RtSceneDev {

@@ -117,6 +117,7 @@ struct RaySet {
     float best[K];
     int slot[K];    // >= 0 sphere slot, INT_MIN none, < 0 plane: -1 - plane slot
     int id[K];      // list index of the hit (filled by merge_planes)
+    float dec[K];   // grouped sweep, shadow rays: a hit nearer than this decides the ray ("not lit"); -inf otherwise
     unsigned pairs_run, heads_run;   // pair records / head records this lane put its rays through (stats)
     unsigned cand_run;               // (ray, sphere) candidates that went to the exact test
 };
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool nearer(const RtSceneDev &sc, float best, int bes
 // of the frame's slowest waves, this path has to be cheap, not just rare.
 template <int K, bool GROUPED>
 __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, const f2 (&q)[K], float bound, float4 A,
-                                           float4 B, int slot0)
+                                           float4 B, int slot0, f2 (&dirx)[K], f2 (&diry)[K], f2 (&dirz)[K])
 {
     const bool second = GROUPED || slot0 + 1 < sc.n_spheres;    // (padding spheres have -r*r = +FLT_MAX: q is never <= bound)
     if constexpr (!GROUPED) {
@@ -222,6 +223,7 @@ __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, c
             if (dist > FLT_EPSILON && nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0)) {
                 r.best[k] = dist;
                 r.slot[k] = slot0;
+                if (dist < r.dec[k]) dirx[k] = diry[k] = dirz[k] = splat(0.0f);
             }
         }
         if (c1 && !(dsq.y > -B.w)) {
@@ -230,6 +232,7 @@ __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, c
             if (dist > FLT_EPSILON && nearer<GROUPED>(sc, r.best[k], r.slot[k], dist, slot0 + 1)) {
                 r.best[k] = dist;
                 r.slot[k] = slot0 + 1;
+                if (dist < r.dec[k]) dirx[k] = diry[k] = dirz[k] = splat(0.0f);
             }
         }
     }
@@ -238,8 +241,8 @@ __device__ __forceinline__ void exact_pair(const RtSceneDev &sc, RaySet<K> &r, c
 // The filter + exact test of K rays against one pair record.
 template <int K, bool GROUPED>
 __device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, const float4 A, const float4 B, int slot0,
-                                          const f2 px, const f2 py, const f2 pz, const f2 (&dx)[K], const f2 (&dy)[K],
-                                          const f2 (&dz)[K], float bound)
+                                          const f2 px, const f2 py, const f2 pz, f2 (&dx)[K], f2 (&dy)[K],
+                                          f2 (&dz)[K], float bound)
 {
     const f2 ux = f2{A.x, A.y} - px, uy = f2{A.z, A.w} - py, uz = f2{B.x, B.y} - pz;
     const f2 uu = pk_fma(uz, uz, pk_fma(uy, uy, ux * ux));
@@ -257,7 +260,7 @@ __device__ __forceinline__ void test_pair(const RtSceneDev &sc, RaySet<K> &r, co
     float m = fminf(q[0].x, q[0].y);
 #pragma unroll
     for (int k = 1; k < K; k++) m = fminf(fminf(m, q[k].x), q[k].y);
-    if (m <= bound) exact_pair<K, GROUPED>(sc, r, q, bound, A, B, slot0);
+    if (m <= bound) exact_pair<K, GROUPED>(sc, r, q, bound, A, B, slot0, dx, dy, dz);
 }
 
 // Grouped sweep: which of the bounding spheres [2*h0, 2*h0 + 2*hn) of `heads` can any ray of this
@@ -389,8 +392,10 @@ __device__ __forceinline__ void sweep_primary(const RtSceneDev &sc, float4 *lds,
                 const f2 s = pk_fma(f2{W.x, W.y}, dz, pk_fma(f2{U.z, U.w}, dy, f2{U.x, U.y} * dx));
                 f2 q[1];
                 q[0] = pk_fma(-s, s, f2{W.z, W.w});
-                if (fminf(q[0].x, q[0].y) <= bound)
-                    exact_pair<1, false>(sc, r, q, bound, lds[2 * p], lds[2 * p + 1], 2 * (base + p));
+                if (fminf(q[0].x, q[0].y) <= bound) {
+                    f2 ex[1] = {dx}, ey[1] = {dy}, ez[1] = {dz};    // (unused by the flat sweep's exact test)
+                    exact_pair<1, false>(sc, r, q, bound, lds[2 * p], lds[2 * p + 1], 2 * (base + p), ex, ey, ez);
+                }
             }
         }
     }
@@ -450,15 +455,25 @@ __device__ __forceinline__ void trace_group(const RtSceneDev &sc, float4 *lds, i
         r.d[0] = refl;
         r.dn[0] = normalize(refl);                                       // sceneobjects.h:71
         r.act[0] = want_refl;
+        r.dec[0] = -INFINITY;
     }
 #pragma unroll
     for (int k = kFirst; k < K; k++) {
         const RtEmitterDev em = sc.emit[sc.emit[e0 + k - kFirst].order];
-        const V3 edir = normalize(v3(em.cx, em.cy, em.cz) - pos);       // GetRayFrom, main.cpp:114
+        const V3 ev = v3(em.cx, em.cy, em.cz) - pos;
+        const V3 edir = normalize(ev);                                   // GetRayFrom, main.cpp:114
         r.o[k] = pos + edir * 0.001f;                                    // main.cpp:121
         r.d[k] = edir;
         r.dn[k] = normalize(edir);
         r.act[k] = on;
+        // The shadow ray is lit only if the emitter itself is the nearest hit, and the emitter cannot be
+        // hit nearer than |c - pos| - r: any hit clearly in front of that decides "not lit", and a
+        // decided ray stops asking for groups (grouped sweep; its direction is zeroed in exact_pair).
+        // The allowance covers the 0.001 step to the origin and the rounding of both distances.
+        if (GROUPED) {
+            const float L = __builtin_amdgcn_sqrtf(dot(ev, ev));
+            r.dec[k] = (L - em.radius) - (0.01f + 0x1p-10f * (L + em.radius));
+        }
     }
     sweep<K, CHUNKED, GROUPED>(sc, lds, cap, on, pos, r);
     merge_planes<K>(sc, on, r);
@@ -677,6 +692,7 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
             }
             r.dn[0] = normalize(r.d[0]);                                     // sceneobjects.h:71
             r.act[0] = in_image;
+            r.dec[0] = -INFINITY;
             if constexpr (GROUPED) {
                 sweep<1, false, true>(sc, lds, cap, in_image, r.o[0], r);
             } else if (fr.lens_on) {
