@@ -279,7 +279,7 @@ def main():
                                  "count over this kernel's time; HBM traffic is the framebuffer only (4 B/px)"},
         }
         if world == 1 and (args.scene, W, H, args.depth, args.spp, args.mode) == ("grid1k", 3840, 2160, 5, 4, "exact"):
-            prof = os.path.join(ROOT, "profiles", "r1", "v4_grouped_grid1k.csv" if grouped else "v4_flat_grid1k.csv")
+            prof = os.path.join(ROOT, "profiles", "r1", "v5_grouped_grid1k.csv" if grouped else "v4_flat_grid1k.csv")
             tag = "trace_sweep_kernel<false, false, false, 6, false, true>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, false>"
             out["roofline"]["traffic"] = profiled_traffic(prof, tag)
             out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE + WRITE_SIZE, uncorrected) from "
