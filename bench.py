@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="frames in flight per rank (each lane: its own context, stream and band buffer); 0 = 1 for one "
                          "GPU, 2 for N > 1 so that the gather of frame k runs under the render of frame k + 1")
+    ap.add_argument("--plan", default="bands", choices=["bands", "strips"],
+                    help="N > 1: contiguous cost-balanced row bands (default; measured the better of the two), or "
+                         "8-column strips dealt round-robin to the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
@@ -141,15 +144,28 @@ def main():
     ctx = capi.Context(local)
     ctx.upload_scene(objs, cam)
 
-    # band plan: identical on every rank (deterministic pre-pass), no communication
-    if world > 1:
-        cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
-        bounds = multigpu.plan_bands(cost, H, world)
+    # the plan is identical on every rank without communication: contiguous row bands balanced by a
+    # deterministic 1/16-resolution pre-pass, or strips of 8 columns dealt round-robin (every rank gets
+    # the same share of every row; no pre-pass, but measured no better: DESIGN.md section 5)
+    strips = world > 1 and args.plan == "strips"
+    out_w = W
+    if strips:
+        bounds = None
+        part = dict(interleave=(world, rank))
+        max_rows = H
+        out_w = capi.interleaved_count(W, world, 0)          # the widest share: equal counts for the gather
+        if capi.interleaved_count(W, world, rank) != out_w:
+            raise SystemExit("bench.py --plan strips wants equal shares: width must be a multiple of 8 x gpus")
     else:
-        bounds = [0, H]
-    y0, y1 = bounds[rank], bounds[rank + 1]
-    max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
-    band = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)       # RGBA8 words
+        if world > 1:
+            cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
+            bounds = multigpu.plan_bands(cost, H, world)
+        else:
+            bounds = [0, H]
+        part = dict(rows=(bounds[rank], bounds[rank + 1]))
+        max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
+    strip_index = {}
+    band = torch.zeros((max_rows, out_w), dtype=torch.int32, device=dev)   # RGBA8 words
     ctx.bind_framebuffer(capi.RT_OUT_RGBA8, band.data_ptr(), band.numel() * 4)
     frame = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
 
@@ -157,7 +173,7 @@ def main():
     offsets = None if args.spp in (1, 4) else capi.stratified_offsets(args.spp)
 
     # ray census of this rank's band (untimed)
-    ctx.render(capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, stats=True, sweep=sweep))
+    ctx.render(capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, stats=True, sweep=sweep, **part))
     st = ctx.stats()
     n_sph = sum(1 for o in objs if o.type == capi.RT_OBJ_SPHERE)
     n_pl = len(objs) - n_sph
@@ -169,7 +185,7 @@ def main():
     brute_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
     grouped = st["group_tests_run"] > 0
 
-    params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=sweep)
+    params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, sweep=sweep, **part)
 
     # Lanes: frames in flight on this rank.  A lane owns a context (a context's renders share scratch and
     # must follow one another on one stream), a stream, a band buffer and, on rank 0, a frame.  With two
@@ -200,10 +216,16 @@ def main():
             if world == 1:
                 f.copy_(b, non_blocking=True)               # the N = 1 "assembly"
             if world > 1 and not rehearsal:
-                multigpu.gather_bands(b, bounds, rank, world, out=f)
+                if strips:
+                    multigpu.gather_strips(b, W, rank, world, out=f, index_cache=strip_index)
+                else:
+                    multigpu.gather_bands(b, bounds, rank, world, out=f)
         if world > 1 and rehearsal:
             stream.synchronize()
-            host = multigpu.gather_bands(b.cpu(), bounds, rank, world)
+            if strips:
+                host = multigpu.gather_strips(b.cpu(), W, rank, world, index_cache=strip_index)
+            else:
+                host = multigpu.gather_bands(b.cpu(), bounds, rank, world)
             if rank == 0:
                 f.copy_(host)
 
@@ -264,7 +286,7 @@ def main():
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                                                                          "sphere_tests", "sphere_tests_run", "group_tests_run", "exact_tests_run")},
                        "lanes": n_lanes,
-                       "parallelism": f"row-bands x{world}" + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
+                       "parallelism": (f"8-column strips round-robin x{world}" if strips else f"row-bands x{world}") + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": None,
@@ -287,7 +309,7 @@ def main():
                                                "(register spill + per-segment record) traffic, served by L2 / Infinity Cache")
         if world == 1 and grouped:
             # the same frame through the flat sweep (north_star's every-ray-tests-every-sphere kernel)
-            pf = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, rows=(y0, y1), mode=mode, sweep=capi.RT_SWEEP_FLAT)
+            pf = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, sweep=capi.RT_SWEEP_FLAT, **part)
             b = ctx.stats()
             for _ in range(3):
                 ctx.render(pf)

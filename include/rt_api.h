@@ -145,7 +145,22 @@ typedef struct rt_render_params {
                                accum_index; needs RT_OUT_F32X4, whose w then is that mean of 1 instead
                                of the ray count; RGBA8 is the quantised mean (main.cpp:44-72)          */
     int32_t accum_index;    /* currentSample: 0 for the first frame (which ignores the old content)   */
+    /* Multi-GPU without a cost estimate: the image is cut into vertical strips of RT_STRIP_COLS columns
+     * and strip s belongs to the render with col_phase == s % col_interleave, so that every render
+     * gets the same share of every row, cheap or expensive (the reference deals its rows to threads,
+     * main.cpp:193-196; here rows near the horizon cost 12x the average, columns do not differ).  The output
+     * planes then are rt_interleaved_count(width, n, phase) pixels wide: this render's strips side by
+     * side.  Combines with row_begin/row_end.  0 or 1 = off. */
+    int32_t col_interleave;
+    int32_t col_phase;
+    /* Scheduling hint, no effect on the image: the tile rows are launched starting at this image row and
+     * wrap around.  A frame's slowest waves (rays grazing the plane at the horizon take 10x the average)
+     * finish under the rest of the frame when they are launched first instead of wherever the horizon
+     * happens to be; rt_split_bands' cost map tells where that is.  0 = top row first. */
+    int32_t first_row;
 } rt_render_params;
+
+#define RT_STRIP_COLS 8
 
 typedef struct rt_stats {
     uint64_t primary_rays;      /* W * rows * spp                                                 */
@@ -222,6 +237,11 @@ const char *rt_last_error(rt_context *ctx);   /* ctx may be NULL: last rt_create
 int rt_api_version(void);
 
 /* ---- host-side helpers (no device needed) ------------------------------------------------ */
+
+/* Columns a render with (col_interleave, col_phase) = (n, phase) produces for an image `width` pixels
+ * wide, and (rt_interleaved_index) the image column its output column `k` is.  Host only. */
+int32_t rt_interleaved_count(int32_t width, int32_t n, int32_t phase);
+int32_t rt_interleaved_index(int32_t k, int32_t n, int32_t phase);
 
 /* The Camera constructor, camera.h:18-45 (double tan, float elsewhere). */
 void rt_camera_init(rt_camera *cam, const float position[3], const float dir[3], float fov_degrees,

@@ -20,6 +20,7 @@ RT_OUT_RGBA8, RT_OUT_F32X4, RT_OUT_COST = 1, 2, 4
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
 RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2
+RT_STRIP_COLS = 8
 RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
 
 
@@ -49,7 +50,8 @@ class RenderParams(C.Structure):
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("outputs", C.c_int32),
                 ("mode", C.c_int32), ("collect_stats", C.c_int32), ("sweep", C.c_int32),
                 ("lens_offsets", C.POINTER(C.c_float)), ("focal_length", C.c_float),
-                ("accumulate", C.c_int32), ("accum_index", C.c_int32)]
+                ("accumulate", C.c_int32), ("accum_index", C.c_int32),
+                ("col_interleave", C.c_int32), ("col_phase", C.c_int32), ("first_row", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -61,7 +63,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_plan_groups", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
+    "rt_create", "rt_destroy", "rt_plan_groups", "rt_interleaved_count", "rt_interleaved_index", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
     "rt_pack_framebuffer", "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
     "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
     "rt_make_scene", "rt_split_bands", "rt_write_bmp", "rt_bmp_header",
@@ -80,6 +82,10 @@ def _load():
     lib.rt_destroy.restype = None
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Object), i32, C.POINTER(Camera)]
     lib.rt_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.rt_interleaved_count.argtypes = [i32, i32, i32]
+    lib.rt_interleaved_count.restype = i32
+    lib.rt_interleaved_index.argtypes = [i32, i32, i32]
+    lib.rt_interleaved_index.restype = i32
     lib.rt_plan_groups.argtypes = [C.POINTER(Object), i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.POINTER(i32)]
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
@@ -186,8 +192,10 @@ def stratified_offsets(spp=16, seed=0x16A11CE):
 
 
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
-                  mode=RT_MODE_EXACT, stats=False, sweep=0, lens=None, focal_length=0.0, accumulate=None):
-    """lens: spp x 2 lens-plane offsets (thin-lens depth of field) with focal_length; accumulate: k
+                  mode=RT_MODE_EXACT, stats=False, sweep=0, lens=None, focal_length=0.0, accumulate=None,
+                  interleave=None, first_row=0):
+    """interleave: (n, phase) = render the 8-column strips s with s % n == phase, side by side (multi-GPU);
+    lens: spp x 2 lens-plane offsets (thin-lens depth of field) with focal_length; accumulate: k
     (currentSample) for the progressive running mean, None = overwrite."""
     p = RenderParams()
     p.width, p.height, p.max_depth, p.spp = width, height, max_depth, spp
@@ -207,6 +215,9 @@ def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, ou
         p.focal_length = float(focal_length)
     if accumulate is not None:
         p.accumulate, p.accum_index = 1, int(accumulate)
+    if interleave is not None:
+        p.col_interleave, p.col_phase = int(interleave[0]), int(interleave[1])
+    p.first_row = int(first_row)
     p._keep = (keep, keep_lens)  # keep the arrays alive as long as the struct
     return p
 
@@ -318,6 +329,11 @@ def tiled_plane(origin, normal, white=None, black=None):
     o.mat = white if white is not None else material((1, 1, 1), (1, 1, 1), 0.6)
     o.mat2 = black if black is not None else material((0, 0, 0), (0, 0, 0), 0.6)
     return o
+
+
+def interleaved_count(width, n, phase):
+    """Width of the planes a render with interleave=(n, phase) produces (rt_interleaved_count)."""
+    return int(lib.rt_interleaved_count(width, n, phase))
 
 
 def plan_groups(objs):

@@ -639,6 +639,14 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     if (y0 == 0 && y1 == 0) y1 = p->height;
     if (y0 < 0 || y1 > p->height || y0 > y1)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad row range [%d,%d) for height %d", y0, y1, p->height);
+    if (p->first_row < 0 || p->first_row >= p->height)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: first_row %d outside the image", p->first_row);
+    const bool strips = p->col_interleave > 1;
+    if (p->col_interleave < 0 || (strips && (p->col_phase < 0 || p->col_phase >= p->col_interleave)))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad col_interleave/col_phase %d/%d", p->col_interleave, p->col_phase);
+    if (strips && ctx->simple_kernel)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: the transcription kernel (RT_AMD_KERNEL=simple) has no col_interleave");
+    const int out_width = strips ? rt_interleaved_count(p->width, p->col_interleave, p->col_phase) : p->width;
     if (p->mode != RT_MODE_EXACT && p->mode != RT_MODE_FAST)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", p->mode);
     if (p->sweep != RT_SWEEP_AUTO && p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
@@ -656,7 +664,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: the transcription kernel (RT_AMD_KERNEL=simple) has no lens/accumulate options");
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t px = (size_t)p->width * (size_t)(y1 - y0);
+    const size_t px = (size_t)out_width * (size_t)(y1 - y0);
     ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
     if (outputs & RT_OUT_RGBA8) {
         int rc = ensure_plane(ctx, 0, px * 4 ? px * 4 : 4);
@@ -670,10 +678,12 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     RtFrameDev fr = {};
     fr.rgba8 = (uint32_t *)ctx->cur_plane[0];
     fr.f32x4 = (float4 *)ctx->cur_plane[1];
-    fr.width = p->width;
+    fr.width = out_width;                                    // of the output planes
     fr.height = p->height;
     fr.row_begin = y0;
     fr.row_end = y1;
+    fr.strip_stride = strips ? p->col_interleave : 0;
+    fr.strip_phase = strips ? p->col_phase : 0;
     fr.max_depth = p->max_depth;
     fr.spp = p->spp;
     fr.inv_spp = 1.0f / (float)p->spp;                       // main.cpp:210
@@ -710,6 +720,7 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
         fr.tile_w = kTile[lg][0];
         fr.tile_h = kTile[lg][1];
     }
+    if (p->first_row > y0 && p->first_row < y1) fr.first_tile_row = (p->first_row - y0) / fr.tile_h;   // launch order only
     // ... else the sample split: spp waves per tile, their sums resolved in order afterwards.  Worth its buffer
     // traffic (32 B per sample and pixel) on scenes whose sweeps are long (rt_sweep_can_split_samples);
     // capped at 1 GiB.

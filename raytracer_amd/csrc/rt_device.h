@@ -88,6 +88,9 @@ struct RtFrameDev {
     // lane per (pixel, sample); the samples of a pixel are summed in order across lanes.  tile_w x tile_h
     // is the pixel footprint (8x8 when off).
     int32_t lane_samples, tile_w, tile_h;
+    int32_t strip_stride, strip_phase;   // rt_render_params.col_interleave/col_phase (stride 0 = off): `width` is the
+                          // width of the output planes, whose column k is image column ((k / 8) * stride + phase) * 8 + k % 8
+    int32_t first_tile_row;   // rt_render_params.first_row in tile rows of this band: launch order only
     int32_t cost_w;       // stats kernels: f32x4.w = work estimate instead of the ray count (RT_OUT_COST)
 };
 

@@ -3,6 +3,7 @@
 // Built with -ffp-contract=off: the camera basis and generated scenes feed bit-exact parity tests.
 #include "rt_api.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -116,6 +117,20 @@ void grid_scene(std::vector<rt_object> &v, int side, uint32_t seed, bool all_ref
 extern "C" {
 
 int rt_api_version(void) { return RT_API_VERSION; }
+
+int32_t rt_interleaved_count(int32_t width, int32_t n, int32_t phase)
+{
+    if (width <= 0 || n < 1 || phase < 0 || phase >= n) return 0;
+    const int32_t strips = (width + RT_STRIP_COLS - 1) / RT_STRIP_COLS;
+    int32_t cols = 0;
+    for (int32_t s = phase; s < strips; s += n) cols += std::min<int32_t>(RT_STRIP_COLS, width - s * RT_STRIP_COLS);
+    return cols;
+}
+
+int32_t rt_interleaved_index(int32_t k, int32_t n, int32_t phase)
+{
+    return ((k / RT_STRIP_COLS) * n + phase) * RT_STRIP_COLS + k % RT_STRIP_COLS;
+}
 
 // Camera::Camera, camera.h:18-45
 void rt_camera_init(rt_camera *cam, const float position[3], const float dir[3], float fov_degrees,

@@ -633,10 +633,15 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
     const int tile = split ? unit / fr.spp : unit;
     const int lane_sample = ls ? lane & (ls - 1) : 0, lane_pixel = ls ? lane / ls : lane;
     const int s_begin = split ? unit - tile * fr.spp : lane_sample, s_end = (split || ls) ? s_begin + 1 : fr.spp;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tx = tile % tiles_x;
+    int ty = tile / tiles_x + fr.first_tile_row;                             // launch order: hot rows first
+    if (ty >= tiles_y && tile < tiles_x * tiles_y) ty -= tiles_y;
     const int x = tx * fr.tile_w + lane_pixel % fr.tile_w;
     const int yr = ty * fr.tile_h + lane_pixel / fr.tile_w;
     const int y = fr.row_begin + yr;
+    // column strips dealt round-robin to several renders: x is the column of the (narrower) output planes,
+    // x_img the image column the ray goes through (tiles are at most RT_STRIP_COLS wide: none straddles strips)
+    const int x_img = fr.strip_stride ? (((x >> 3) * fr.strip_stride + fr.strip_phase) << 3) + (x & 7) : x;
     const bool in_image = (tile < tiles_x * tiles_y) && x < fr.width && yr < rows;
 
     const V3 cam_pos = v3(cam.position[0], cam.position[1], cam.position[2]);
@@ -669,7 +674,7 @@ __global__ __launch_bounds__((GROUPED || (!CHUNKED && !COMPACT)) ? 64 : kBlock, 
         bool alive;
         {
             // Camera::GetWorldRay, camera.h:48-62
-            float sx = (float)x + smp.xy[2 * s], sy = (float)y + smp.xy[2 * s + 1];   // main.cpp:205
+            float sx = (float)x_img + smp.xy[2 * s], sy = (float)y + smp.xy[2 * s + 1];   // main.cpp:205
             float px = ((sx * 2.0f) / cam.image_width) - 1.0f;
             float py = ((sy * 2.0f) / cam.image_height) - 1.0f;
             V3 d = cam_view;

@@ -1,7 +1,8 @@
 """Row-band partitioning of one frame over the ranks of a node (one process per GPU).
 
 The reference's only parallel axis is image rows over std::threads (raytracer_cpp/main.cpp:193-196);
-here rows are cut into contiguous bands, one per GPU, balanced by a cost estimate from a
+two plans: (a) 8-column strips dealt round-robin to the GPUs (render_params(interleave=...), gather_strips): no cost
+estimate needed, every GPU gets the same share of every row, cheap or expensive; (b) rows cut into contiguous bands, one per GPU, balanced by a cost estimate from a
 1/16-resolution pre-pass (the F32X4 plane's w channel with RT_OUT_COST = the tests each pixel's rays
 took, exact tests weighted: rays near the horizon cost an order of magnitude more than the average).  Every rank runs the
 same deterministic pre-pass, so all ranks agree on the bounds without communication.  The only
@@ -44,9 +45,57 @@ def prepass_row_cost(ctx, objs, cam, width, height, max_depth, factor=4):
     return row_cost_from_prepass(f32[..., 3], height)
 
 
+def hot_row(row_cost, lead=16):
+    """Where to start launching (rt_render_params.first_row): a little above the most expensive row of the
+    cost map, so that the frame's slowest waves run under the rest of the frame instead of after it."""
+    c = np.asarray(row_cost, dtype=np.float64)
+    return int(max(0, int(np.argmax(c)) - lead)) if c.size else 0
+
+
 def plan_bands(row_cost, height, world):
     """Contiguous bands of near-equal cost: list of world+1 row boundaries (rt_split_bands)."""
     return capi.split_bands(height, world, row_cost)
+
+
+def interleaved_col_index(width, world, rank):
+    """Image columns of rank's strips, in the order its render lays them side by side
+    (rt_interleaved_index): strips of capi.RT_STRIP_COLS columns dealt round-robin, strip s to rank s % world."""
+    s = capi.RT_STRIP_COLS
+    strips = np.arange(rank, -(-width // s), world)
+    cols = (strips[:, None] * s + np.arange(s)[None, :]).reshape(-1)
+    return cols[cols < width]
+
+
+def gather_strips(part, width, rank, world, out=None, group=None, index_cache=None):
+    """Gathers interleaved renders (render_params(interleave=(world, rank))) to rank 0 and puts every strip
+    in its place.  part: torch tensor [rows, max_cols, ...] whose first interleaved_count(width, world, rank)
+    columns are this rank's output; all ranks pass the same max_cols = interleaved_count(width, world, 0)
+    (a render's own planes are exactly its count wide: when the shares differ, i.e. width is not a multiple of
+    8 x world, copy them into the padded tensor first; with equal shares the render can write into it directly).
+    Returns the assembled [rows, width, ...] tensor on rank 0 (written into `out` when given), else None.
+    index_cache: a dict the caller keeps between frames (the column indices live on the tensor's device)."""
+    import torch
+    import torch.distributed as dist
+
+    parts = None
+    if world > 1:
+        if rank == 0:
+            parts = [torch.empty_like(part) for _ in range(world)]
+        dist.gather(part, parts, dst=0, group=group)
+        if rank != 0:
+            return None
+    else:
+        parts = [part]
+    if out is None:
+        out = torch.empty((part.shape[0], width) + tuple(part.shape[2:]), dtype=part.dtype, device=part.device)
+    cache = index_cache if index_cache is not None else {}
+    for r in range(world):
+        key = (width, world, r, str(part.device))
+        if key not in cache:
+            cache[key] = torch.from_numpy(interleaved_col_index(width, world, r).astype(np.int64)).to(part.device)
+        idx = cache[key]
+        out.index_copy_(1, idx, parts[r][:, : idx.numel()])
+    return out
 
 
 def gather_bands(band, bounds, rank, world, out=None, group=None):

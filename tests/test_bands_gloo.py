@@ -75,3 +75,56 @@ def test_band_gather_gloo(world):
     assert bounds[0] == 0 and bounds[-1] == 72 and len(bounds) == world + 1
     heights = [bounds[i + 1] - bounds[i] for i in range(world)]
     assert min(heights) > 0 and len(set(heights)) > 1      # cost-balanced, hence unequal, bands
+
+
+def _strip_worker(rank, world, port, w, h, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import capi, multigpu
+    from oracle import oracle_lib
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+        # this rank's strips, side by side the way render_params(interleave=(world, rank)) lays them out
+        # (the device-side mapping itself is checked on the GPU: test_col_interleave_tiles_the_frame)
+        cols = multigpu.interleaved_col_index(w, world, rank)
+        assert len(cols) == capi.interleaved_count(w, world, rank)
+        full = oracle_lib.render(objs, cam, capi.render_params(w, h, 5, 1), threads=2, want_f32=False)[0]
+        part = torch.zeros((h, capi.interleaved_count(w, world, 0), 3), dtype=torch.uint8)
+        part[:, : len(cols)] = torch.from_numpy(np.ascontiguousarray(full[:, cols]))
+        cache = {}
+        frame = multigpu.gather_strips(part, w, rank, world, index_cache=cache)
+        again = multigpu.gather_strips(part, w, rank, world, index_cache=cache)       # cached indices
+        if rank == 0:
+            q.put(("ok", bool(np.array_equal(frame.numpy(), full) and np.array_equal(again.numpy(), full)), None))
+        else:
+            assert frame is None and again is None
+    except Exception as e:
+        q.put(("err", repr(e), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w", [(2, 96), (3, 91)])
+def test_strip_gather_gloo(world, w):
+    """8-column strips dealt round-robin (rt_render_params.col_interleave): the padded gather and the
+    column scatter on rank 0 rebuild the single-process frame, also when the last strip is narrow and
+    the shares are unequal."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, w, 40, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+        assert p.exitcode == 0
+    status, equal, _ = q.get(timeout=5)
+    assert status == "ok" and equal

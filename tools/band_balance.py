@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""How well do the cost-balanced row bands balance in time?  Renders each band of an N-way split on
-one GPU and prints the kernel time per band (the slowest band sets the N-GPU frame time).
+"""How well do the N-way splits of a frame balance in time?  Renders each part of a split on one GPU
+(cost-balanced bands, equal bands, round-robin strips) and prints the kernel time per part (the slowest
+part sets the N-GPU frame time).
 
     python tools/band_balance.py [--gpus 8] [--scene grid1k] [--width 3840 --height 2160 --spp 4]
 """
@@ -28,16 +29,25 @@ def main():
     ctx = capi.Context(0)
     ctx.upload_scene(objs, cam)
     cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
-    for name, bounds in (("cost-balanced", multigpu.plan_bands(cost, H, args.gpus)), ("equal rows", capi.split_bands(H, args.gpus, None))):
-        ms = []
-        for r in range(args.gpus):
-            p = capi.render_params(W, H, args.depth, args.spp, rows=(bounds[r], bounds[r + 1]))
-            ctx.render(p)
-            ctx.render(p)
-            ms.append(ctx.stats()["kernel_ms"])
-        print(f"{name}: bounds {bounds}")
-        print("  ms per band " + " ".join(f"{m:.2f}" for m in ms) + f" | max {max(ms):.2f}, mean {sum(ms) / len(ms):.2f}, "
+    hot = multigpu.hot_row(cost)
+    print(f"hot row {hot}")
+    def timed(**kw):
+        p = capi.render_params(W, H, args.depth, args.spp, **kw)
+        ctx.render(p)
+        ctx.render(p)
+        return ctx.stats()["kernel_ms"]
+
+    def line(what, ms):
+        print(f"  ms per {what} " + " ".join(f"{m:.2f}" for m in ms) + f" | max {max(ms):.2f}, mean {sum(ms) / len(ms):.2f}, "
               f"max/mean {max(ms) / (sum(ms) / len(ms)):.3f}")
+
+    for first in (0, hot):
+        print(f"first_row {first}: whole frame {timed(first_row=first):.2f} ms")
+        for name, bounds in (("cost-balanced", multigpu.plan_bands(cost, H, args.gpus)), ("equal rows", capi.split_bands(H, args.gpus, None))):
+            print(f" {name}: bounds {bounds}")
+            line("band", [timed(rows=(bounds[r], bounds[r + 1]), first_row=first) for r in range(args.gpus)])
+        print(" 8-column strips dealt round-robin (col_interleave):")
+        line("rank", [timed(interleave=(args.gpus, r), first_row=first) for r in range(args.gpus)])
     ctx.close()
 
 
