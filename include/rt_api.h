@@ -116,8 +116,8 @@ enum {
     RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */
     RT_SWEEP_GROUPED = 2 /* spheres are grouped at upload (8 per group along a Morton curve, 8
-                            groups per super-group); a wave skips a group when the lines of all its
-                            rays miss the group's bounding sphere.  Scenes of fewer than 64 spheres
+                            groups per super-group); a wave skips a group when all its rays pass
+                            the group's bounding sphere at a distance.  Scenes of fewer than 64 spheres
                             take the flat sweep regardless                                         */
 };
 
