@@ -4,9 +4,8 @@
 // (git-ignored).  It exposes the reference's primitives so that tests/gen_golden.py can record
 // known-answer fixtures under tests/golden/ and so that oracle/rt_oracle.c can be validated.
 //
-// raytracer_cpp/main.cpp (TraceRay, DrawScene) is NOT compiled: it includes the un-vendored
-// CmdParser submodule (main.cpp:10) and no stand-in is written for it.  The trace loop is pinned by
-// the reference outputs recorded in SURVEY.md section 8c instead.
+// The trace loop of raytracer_cpp/main.cpp (InitScene, FindNearestObject, TraceRay, DrawScene) is
+// compiled by its own recipe: ref_trace_harness.cpp -> oracle/_ref/libref_trace_d<MAX_DEPTH>.so.
 #include <cassert>
 #include <cstdint>
 #include <cstdlib>

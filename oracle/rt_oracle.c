@@ -426,16 +426,22 @@ void orc_render(const rt_object *objs, int n, const rt_camera *cam, const rt_ren
     free(tid);
 }
 
-void orc_trace_samples(const rt_object *objs, int n, const rt_camera *cam, int max_depth,
-                       const float *sxy, int n_samples, float *rgb_out)
+void orc_trace_samples_v(const rt_object *objs, int n, const rt_camera *cam, int max_depth, int verbatim,
+                         const float *sxy, int n_samples, float *rgb_out)
 {
     v3 cpos = v3_from(cam->position);
     for (int i = 0; i < n_samples; i++) {
         float d[3];
         orc_world_ray(cam, sxy[2 * i], sxy[2 * i + 1], d);
-        v3 c = trace(objs, n, cpos, v3_from(d), 0, max_depth, 0, NULL);
+        v3 c = trace(objs, n, cpos, v3_from(d), 0, max_depth, verbatim, NULL);
         rgb_out[3 * i] = c.x; rgb_out[3 * i + 1] = c.y; rgb_out[3 * i + 2] = c.z;
     }
+}
+
+void orc_trace_samples(const rt_object *objs, int n, const rt_camera *cam, int max_depth,
+                       const float *sxy, int n_samples, float *rgb_out)
+{
+    orc_trace_samples_v(objs, n, cam, max_depth, 0, sxy, n_samples, rgb_out);
 }
 
 /* ---- WriteBitmap, writebitmap.h:88-182 ----------------------------------------------------- */

@@ -5,12 +5,15 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under raytracer_amd/
  * may include, link or call it.
  *
- * Pinning: the restatement reproduces the reference's own outputs recorded in SURVEY.md section
- * 8c (BMP md5 for -a 0 / -a 1, ten float radiance values, camera basis, ray counters) -- see
- * tests/test_oracle_golden.py -- and its primitives are checked against the reference's own
- * headers compiled where they lie (oracle/_ref, built by oracle/Makefile when /root/reference is
- * present) through the fixtures in tests/golden/.  raytracer_cpp/main.cpp itself is NOT buildable
- * here: it includes the un-vendored CmdParser submodule (main.cpp:10, .gitmodules:1-3).
+ * Pinning: PINNED TO THE REFERENCE ITSELF.  oracle/Makefile compiles the reference's own trace loop
+ * (raytracer_cpp/main.cpp's InitScene, FindNearestObject, TraceRay, DrawScene, from the file where it
+ * lies, minus the CmdParser include :10 and main() :230-258, which the loop does not use) and its
+ * headers into the libraries under oracle/_ref; tests/gen_golden.py records their outputs into tests/golden/ (image.bmp
+ * md5s for -a 0 / -a 1, whole-frame radiance hashes, >1000 radiance values, call counters by depth, the
+ * synthetic scenes at MAX_DEPTH 5 and 8, 14 edge scenes at MAX_DEPTH 0/1/5/15, BASELINE's configs 2 and
+ * 3, ~1300 primitive known answers), and tests/test_oracle_golden.py holds this restatement to every
+ * one of them bit for bit -- and, where oracle/_ref is present, to the reference's TraceRay live on
+ * random scenes.
  *
  * It shares only the POD layouts of include/rt_api.h with the product.
  */
@@ -60,6 +63,9 @@ void orc_render(const rt_object *objs, int n, const rt_camera *cam, const rt_ren
 /* Radiance of individual samples (sx, sy in pixel units) -- for sparse-pixel fixtures. */
 void orc_trace_samples(const rt_object *objs, int n, const rt_camera *cam, int max_depth,
                        const float *sxy, int n_samples, float *rgb_out);
+/* The same with the emitter loop as written (verbatim != 0) or pruned (0). */
+void orc_trace_samples_v(const rt_object *objs, int n, const rt_camera *cam, int max_depth, int verbatim,
+                         const float *sxy, int n_samples, float *rgb_out);
 /* writebitmap.h:88-182, byte-identical output */
 int orc_write_bmp(const char *path, int w, int h, const uint8_t *rgb8);
 

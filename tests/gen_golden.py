@@ -6,9 +6,11 @@ from the reference's headers where they lie (raytracer_cpp/sceneobjects.h, camer
 and the vendored GLM) -- see oracle/ref_harness.cpp.  The fixtures are data only: inputs and the
 reference's outputs as IEEE-754 bit patterns.  Nothing of the reference travels to the GPU box.
 
-Also records the reference outputs the survey captured from the real program: BMP
-md5s, ten radiance values, camera basis and ray counters -- those pin the trace loop, which cannot be
-compiled here (raytracer_cpp/main.cpp needs the un-vendored CmdParser submodule).
+The trace loop itself -- InitScene, FindNearestObject, TraceRay, DrawScene of raytracer_cpp/main.cpp --
+is compiled from the reference's file as well (oracle/_ref/libref_trace_d<MAX_DEPTH>.so, see
+oracle/ref_trace_harness.cpp and oracle/Makefile), and every whole-path pin below is COMPUTED from it:
+image.bmp md5s, radiance, call counters, the synthetic scenes at depth 5 and 8, the edge scenes at
+depth 0/1/5/15, the 1080p and 4K-16spp frames of BASELINE's configs 2 and 3.
 
 Usage: make -C oracle && python tests/gen_golden.py
 """
@@ -36,6 +38,163 @@ def bits(a):
 
 def f3(v):
     return F3(*[float(x) for x in v])
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def cam_bits(cam):
+    return bits(list(cam.position) + list(cam.view_direction) + list(cam.right) + list(cam.up) +
+                [cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height])
+
+
+REF_PATTERN = np.array([0.1, 0.2, 0.6, 0.5, 0.8, 0.7, 0.2, 0.8], dtype=np.float32)      # main.cpp:202
+SURVEY_PIXELS = [(0, 0), (1023, 767), (100, 700), (660, 180), (512, 384), (445, 232), (300, 400), (750, 410), (510, 490), (512, 300)]
+
+
+def ref_trace(depth):
+    r = oracle_lib.load_ref_trace(depth)
+    if r is None:
+        raise SystemExit("oracle/_ref/libref_trace_d%d.so missing: run `make -C oracle` where /root/reference exists" % depth)
+    return r
+
+
+def gen_trace_pins(rng):
+    """The reference PROGRAM's path on its own scene: InitScene + DrawScene + WriteBitmap verbatim (what
+    main() does, main.cpp:240-255), radiance through the verbatim TraceRay, and the calls TraceRay makes
+    into the scene objects (counting subclasses of the reference's Sphere/TiledPlane)."""
+    r5 = ref_trace(5)
+    r5.init_scene()
+    objs, n, cam = r5.get_scene(capi.Object, capi.Camera)
+    pins = {"source": "raytracer_cpp/main.cpp compiled in place (oracle/_ref/libref_trace_d*.so): InitScene, DrawScene, "
+                      "WriteBitmap, TraceRay verbatim; default scene, ImageWidth x ImageHeight, MAX_DEPTH 5",
+            "image": [r5.lib.ref_trace_image_width(), r5.lib.ref_trace_image_height()],
+            "init_scene": {"n": n, "objects_sha256": hashlib.sha256(bytes(objs)[: n * C.sizeof(capi.Object)]).hexdigest(),
+                           "camera": cam_bits(cam)}}
+    w, h = pins["image"]
+    md5, rgb_sha, header = {}, {}, None
+    for a in (0, 1):
+        with tempfile.NamedTemporaryFile(suffix=".bmp") as tf:
+            rgb_parts = [r5.draw_scene(tf.name, parts, a) for parts in ((2, 1, 8) if a == 0 else (2,))]   # -p default 2
+            data = open(tf.name, "rb").read()
+        assert all(np.array_equal(rgb_parts[0], x) for x in rgb_parts), "the image depends on -p"
+        md5["a%d" % a] = hashlib.md5(data).hexdigest()
+        rgb_sha["a%d" % a] = sha(rgb_parts[0])
+        header = data[:54]
+        # the harness's own pixel loop (used below for other sizes) must be DrawScene's
+        rgb_f, _ = r5.frame(w, h, 4 if a else 1, REF_PATTERN[: 8 if a else 2])
+        assert np.array_equal(rgb_f, rgb_parts[0]), "ref_trace_frame differs from the verbatim DrawScene"
+    pins["bmp_md5"] = md5
+    pins["rgb8_sha256"] = rgb_sha
+    import struct
+    pins["bmp_header"] = {"bfSize": struct.unpack_from("<I", header, 2)[0], "offBits": struct.unpack_from("<I", header, 10)[0],
+                          "biSize": struct.unpack_from("<I", header, 14)[0], "w": struct.unpack_from("<i", header, 18)[0],
+                          "h": struct.unpack_from("<i", header, 22)[0], "bpp": struct.unpack_from("<H", header, 28)[0],
+                          "biSizeImage": struct.unpack_from("<I", header, 34)[0]}
+    # radiance of single samples at the -a 0 offset (.1, .2): the survey's ten pixels and 1024 random ones
+    px = np.array(SURVEY_PIXELS + [(int(rng.integers(0, w)), int(rng.integers(0, h))) for _ in range(1024)])
+    sxy = (px.astype(np.float32) + REF_PATTERN[:2]).astype(np.float32)
+    rad = r5.trace_samples(sxy)
+    pins["radiance_a0"] = {"pixels": px.reshape(-1).tolist(), "samples": bits(sxy.reshape(-1)), "radiance": bits(rad.reshape(-1))}
+    _, f32 = r5.frame(w, h, 1, REF_PATTERN[:2])
+    pins["f32_rgb_sha256_a0"] = sha(f32[..., :3])
+    _, f32 = r5.frame(w, h, 4, REF_PATTERN)
+    pins["f32_rgb_sha256_a1"] = sha(f32[..., :3])
+    # counters: calls the verbatim loop makes.  Intersects = N * calls + N^2 * hits (main.cpp:71-79 and
+    # :112-151), GetSurfaceNormal = hits (:95), GetRayFrom = N * hits (:114).  Calls by recursion depth
+    # from libraries built with MAX_DEPTH 0..5: a path's first k segments do not depend on MAX_DEPTH.
+    dobjs, dcam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    counters = {}
+    for a in (0, 1):
+        by_limit = []
+        for d in range(6):
+            rd = ref_trace(d)
+            rd.set_scene(dobjs, dcam, counting=True)
+            rd.reset_counters()
+            rd.draw_scene(None, 1, a)
+            c = rd.counters()
+            hits = c["normals"]
+            assert c["ray_from"] == n * hits
+            assert (c["intersects"] - n * n * hits) % n == 0
+            by_limit.append({"calls": (c["intersects"] - n * n * hits) // n, "hits": hits, "intersects": c["intersects"],
+                             "materials": c["materials"]})
+        full = by_limit[5]
+        counters["a%d" % a] = {"calls": full["calls"], "hits": full["hits"], "nearest_tests": n * full["calls"],
+                               "shadow_tests_verbatim": n * n * full["hits"], "shadow_rays_verbatim": n * full["hits"],
+                               "get_material_calls": full["materials"],
+                               "by_depth": [by_limit[0]["calls"]] + [by_limit[d]["calls"] - by_limit[d - 1]["calls"] for d in range(1, 6)]}
+    pins["counters"] = counters
+    ray = F3()
+    ref = oracle_lib.load_ref()
+    ref.ref_world_ray(f3([0, 6, 8]), f3([0, -.8, -1]), C.c_float(60.0), w, h, C.c_float(512.1), C.c_float(384.2), ray)
+    pins["primary_dir_512_384"] = bits(list(ray))
+    json.dump(pins, open(os.path.join(OUT, "trace_pins.json"), "w"))
+
+
+def gen_scene_pins(rng):
+    """Sparse-pixel radiance of the synthetic scenes at BASELINE's full sizes through the verbatim
+    TraceRay (O(N^2) per hit as written: ~20 ms per hit at N = 1029, ~4 s at N = 16393)."""
+    scenes = {}
+    for name, kind, w, h, depth, n_px in (("default", 0, 1024, 768, 5, 192), ("grid1k", 1, 3840, 2160, 5, 192),
+                                          ("grid1k_8k", 1, 7680, 4320, 8, 192), ("grid16k", 2, 3840, 2160, 5, 24)):
+        objs, cam = capi.make_scene(kind, w, h, frame=17)
+        r = ref_trace(depth)
+        r.set_scene(objs, cam)
+        # pixel-aligned samples at the reference's single-sample offset (.1,.2), main.cpp:202-205
+        px = np.stack([rng.integers(0, w, n_px), rng.integers(0, h, n_px)], axis=1)
+        sxy = (px.astype(np.float32) + REF_PATTERN[:2]).astype(np.float32)
+        rad = r.trace_samples(sxy, threads=8)
+        scenes[name] = {"kind": kind, "w": w, "h": h, "depth": depth, "frame": 17, "n": len(objs),
+                        "objects_sha256": hashlib.sha256(bytes(objs)).hexdigest(), "camera": cam_bits(cam),
+                        "pixels": px.reshape(-1).tolist(), "samples": bits(sxy.reshape(-1)), "radiance": bits(rad.reshape(-1))}
+        print("scene pins:", name, flush=True)
+    json.dump({"source": "rt_make_scene + the reference's own TraceRay (oracle/_ref/libref_trace_d5/d8.so); "
+                         "full-resolution sparse-pixel pins", "scenes": scenes}, open(os.path.join(OUT, "scenes.json"), "w"))
+
+
+def gen_edge_pins():
+    """Whole small frames of tests/edge_scenes.py through the reference's TraceRay at MAX_DEPTH 0/1/5/15,
+    spp 1 and 4: sha256 of the radiance bits and of the 8-bit image, plus a few radiance values to look at."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edge_scenes
+    out = {}
+    for depth, (w, h) in edge_scenes.CASES:
+        r = ref_trace(depth)
+        cam = capi.camera_init(*edge_scenes.CAMERA, w, h)
+        for name, items in edge_scenes.edge_scenes(capi).items():
+            objs = capi.objects(items)
+            r.set_scene(objs, cam)
+            for spp in (1, 4):
+                rgb, f32 = r.frame(w, h, spp, REF_PATTERN[: 2 * spp])
+                out["%s/d%d/%dx%d/spp%d" % (name, depth, w, h, spp)] = {
+                    "objects_sha256": hashlib.sha256(bytes(objs)).hexdigest(), "f32_rgb_sha256": sha(f32[..., :3]),
+                    "rgb8_sha256": sha(rgb), "first_row": bits(f32[0, : min(w, 8), :3].reshape(-1))}
+    json.dump({"source": "tests/edge_scenes.py rendered by the reference's own TraceRay (oracle/_ref/libref_trace_d*.so) inside "
+                         "DrawScene's pixel loop; camera = InitScene's", "frames": out}, open(os.path.join(OUT, "edge_scenes.json"), "w"))
+
+
+def gen_config_pins():
+    """BASELINE configs 2 and 3 on the default scene through the reference's TraceRay: the whole 1920x1080
+    frame at -a 0 and -a 1, and rows 1200-1296 of the 3840x2160 frame with config 3's 16 stratified samples."""
+    r = ref_trace(5)
+    out = {}
+    w, h = 1920, 1080
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    r.set_scene(objs, cam)
+    for spp in (1, 4):
+        rgb, f32 = r.frame(w, h, spp, REF_PATTERN[: 2 * spp])
+        out["config2/spp%d" % spp] = {"w": w, "h": h, "depth": 5, "spp": spp, "rows": [0, h], "f32_rgb_sha256": sha(f32[..., :3]),
+                                      "rgb8_sha256": sha(rgb)}
+    w, h, rows = 3840, 2160, (1200, 1296)
+    off = capi.stratified_offsets(16)
+    objs, cam = capi.make_scene(capi.RT_SCENE_DEFAULT, w, h)
+    r.set_scene(objs, cam)
+    rgb, f32 = r.frame(w, h, 16, off, rows=rows)
+    out["config3/band"] = {"w": w, "h": h, "depth": 5, "spp": 16, "rows": list(rows), "offsets": bits(np.asarray(off).reshape(-1)),
+                           "f32_rgb_sha256": sha(f32[rows[0]:rows[1], :, :3]), "rgb8_sha256": sha(rgb[rows[0]:rows[1]])}
+    json.dump({"source": "default scene through the reference's own TraceRay (oracle/_ref/libref_trace_d5.so) inside DrawScene's "
+                         "pixel loop", "frames": out}, open(os.path.join(OUT, "config_frames.json"), "w"))
 
 
 def main():
@@ -157,49 +316,10 @@ def main():
     json.dump({"source": "WriteBitmap via oracle/_ref; image = default_rng(seed).integers(0,256,(h,w,3),uint8)", "rows": rows},
               open(os.path.join(OUT, "bmp.json"), "w"))
 
-    # ---- reference program outputs recorded by the survey ----
-    survey = {
-        "source": "SURVEY.md sections 6 and 8c: outputs of the verbatim raytracer_cpp program, default scene 1024x768 depth 5",
-        "bmp_md5": {"a0": "14fde7512af4d3ff28fca8df037d2cde", "a1": "1ca90b11700b443f2b4c52af5823bbfb"},
-        "bmp_header": {"bfSize": 2359350, "offBits": 54, "biSize": 40, "w": 1024, "h": 768, "bpp": 24, "biSizeImage": 2359296},
-        "camera": {"up": [0.0, float.fromhex("0x1.8fce08p-1"), float.fromhex("-0x1.3fd806p-1")],
-                   "view": [0.0, float.fromhex("-0x1.3fd806p-1"), float.fromhex("-0x1.8fce08p-1")],
-                   "half": float.fromhex("0x1.279a74p-1"), "aspect": float.fromhex("0x1.555556p+0")},
-        "radiance_a0": {
-            "0,0": ["0x1.89374cp-6"] * 3, "1023,767": ["0x1.89374cp-6"] * 3, "100,700": ["0x1.89374cp-6"] * 3,
-            "660,180": ["0x1.89374cp-6"] * 3,
-            "512,384": ["0x1.e136f2p-4", "0x1.1db498p-6", "0x1.5aa50cp-7"],
-            "445,232": ["0x1.03fc8ep+0", "0x1.c6e97cp-2", "0x1.616632p-2"],
-            "300,400": ["0x1.ee193cp-3", "0x1.a0488ap-6", "0x1.a0abd0p-3"],
-            "750,410": ["0x1.d043a8p+0", "0x1.d043a8p+0", "0x1.a08752p-1"],
-            "510,490": ["0x0p+0", "0x1.b44948p-3", "0x1.84706ep-1"],
-            "512,300": ["0x1.baebe8p-3", "0x1.2733e0p-5", "0x1.2733e0p-5"]},
-        "primary_dir_512_384": ["0x1.3b3bb8p-13", "-0x1.3ff6cep-1", "-0x1.8fb56cp-1"],
-        "counters_a1": {"calls": 6752898, "hits": 3791785, "by_depth": [3145728, 3058819, 353060, 121998, 47328, 25965],
-                        "nearest_tests": 40517388, "shadow_tests_verbatim": 136504260, "shadow_tests_pruned": 45501420,
-                        "shadow_rays_verbatim": 22750710, "shadow_rays_pruned": 7583570, "lit": 5472647},
-        "counters_a0": {"calls": 1688209, "hits": 947931, "nearest_tests": 10129254, "shadow_tests_verbatim": 34125516},
-    }
-    json.dump(survey, open(os.path.join(OUT, "survey_pins.json"), "w"), indent=1)
-
-    # ---- scene generator hashes + sparse radiance of the synthetic scenes (from the pinned oracle) ----
-    scenes = {}
-    for name, kind, w, h, depth in (("default", 0, 1024, 768, 5), ("grid1k", 1, 3840, 2160, 5), ("grid1k_8k", 1, 7680, 4320, 8),
-                                    ("grid16k", 2, 3840, 2160, 5)):
-        objs, cam = capi.make_scene(kind, w, h, frame=17)
-        blob = bytes(objs)
-        # pixel-aligned samples at the reference's single-sample offset (.1,.2), main.cpp:202-205
-        px = np.stack([rng.integers(0, w, 192), rng.integers(0, h, 192)], axis=1)
-        sxy = (px.astype(np.float32) + np.array([0.1, 0.2], dtype=np.float32)).astype(np.float32)
-        rad = oracle_lib.trace_samples(objs, cam, depth, sxy)
-        scenes[name] = {"kind": kind, "w": w, "h": h, "depth": depth, "frame": 17, "n": len(objs),
-                        "objects_sha256": hashlib.sha256(blob).hexdigest(),
-                        "camera": bits(list(cam.position) + list(cam.view_direction) + list(cam.right) + list(cam.up) +
-                                       [cam.aspect_ratio, cam.half_angle, cam.image_width, cam.image_height]),
-                        "pixels": px.reshape(-1).tolist(),
-                        "samples": bits(sxy.reshape(-1)), "radiance": bits(rad.reshape(-1))}
-    json.dump({"source": "rt_make_scene + the pinned oracle (orc_trace_samples); full-resolution sparse-pixel pins",
-               "scenes": scenes}, open(os.path.join(OUT, "scenes.json"), "w"))
+    gen_trace_pins(rng)
+    gen_scene_pins(rng)
+    gen_edge_pins()
+    gen_config_pins()
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -91,7 +91,7 @@ def test_host_program_fails_loudly_without_gpu(tmp_path):
 def test_host_program_writes_reference_image(tmp_path, args, key):
     """raytracer_cpp's CLI contract: defaults -p 2 -a 1, image.bmp in the working directory, whose
     md5 is the one the verbatim program produced."""
-    pins = json.load(open(os.path.join(GOLD, "survey_pins.json")))
+    pins = json.load(open(os.path.join(GOLD, "trace_pins.json")))
     r = subprocess.run([MAIN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("Time: ")
