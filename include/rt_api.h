@@ -232,6 +232,24 @@ int rt_set_stream(rt_context *ctx, void *stream);
 int rt_render_async(rt_context *ctx, const rt_render_params *params);
 int rt_sync(rt_context *ctx);
 
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  A variant of rt_render_async that allocates
+ * nothing -- no hipMalloc/hipFree, no event or buffer creation -- and enqueues the same kernels: the
+ * caller passes the output planes as device pointers (16-byte aligned; the plane that params->outputs
+ * does not ask for may be NULL), and what rt_render_async keeps in buffers of its own -- the sample-split
+ * plane (16 B per sample and pixel, used by the flat sweep of scenes of 48 spheres or more and by spp
+ * that are not a power of two) and the ray counters -- lives in a fixed RT_NOALLOC_SCRATCH_BYTES array in
+ * device memory that each GPU the library runs on holds until the process ends.  A render whose
+ * sample-split plane exceeds it fails with RT_ERR_LIMIT (render fewer rows per call, or use rt_render);
+ * renders that need no such plane have no size limit.  Every call on one GPU shares that GPU's array,
+ * whichever context it comes from: calls that overlap on one GPU race; calls on one stream do not.
+ * Returns without waiting (rt_sync, or the caller's stream); kernel_ms is not measured for these
+ * renders.  The scene must have been uploaded (rt_upload_scene allocates; do that outside the loop). */
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+#define RT_NOALLOC_STATS_BYTES 256u
+int rt_render_noalloc(rt_context *ctx, const rt_render_params *params, void *rgba8_dev, size_t rgba8_bytes,
+                      void *f32x4_dev, size_t f32x4_bytes);
+
 int rt_get_stats(rt_context *ctx, rt_stats *out);
 const char *rt_last_error(rt_context *ctx);   /* ctx may be NULL: last rt_create failure         */
 int rt_api_version(void);

@@ -65,7 +65,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_plan_groups", "rt_interleaved_count", "rt_interleaved_index", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
     "rt_pack_framebuffer", "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
-    "rt_sync", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
+    "rt_sync", "rt_render_noalloc", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
     "rt_make_scene", "rt_split_bands", "rt_write_bmp", "rt_bmp_header",
 ]
 
@@ -91,6 +91,7 @@ def _load():
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_sync.argtypes = [vp]
+    lib.rt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_size_t, vp, C.c_size_t]
     lib.rt_download_framebuffer.argtypes = [vp, vp, C.c_size_t, i32]
     lib.rt_pack_framebuffer.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rt_framebuffer_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -258,6 +259,11 @@ class Context:
 
     def sync(self):
         self._check(lib.rt_sync(self._h))
+
+    def render_noalloc(self, params, rgba8_ptr, rgba8_bytes, f32x4_ptr=0, f32x4_bytes=0):
+        """rt_render_noalloc: enqueue-only render into caller-owned device planes, allocating nothing."""
+        self._check(lib.rt_render_noalloc(self._h, C.byref(params), C.c_void_p(rgba8_ptr or None), C.c_size_t(rgba8_bytes),
+                                          C.c_void_p(f32x4_ptr or None), C.c_size_t(f32x4_bytes)))
 
     def stream(self):
         s = C.c_void_p()

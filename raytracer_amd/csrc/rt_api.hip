@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -49,6 +50,8 @@ struct rt_context {
     void *pack_buf = nullptr;         // staging for the 24-bit download formats
     size_t pack_bytes = 0;
     RtStatsDev *stats_dev = nullptr;
+    void *scratch_dev = nullptr;      // this device's copy of `scratch` (rt_render_noalloc)
+    const RtStatsDev *stats_src = nullptr;   // where the last render's counters are: stats_dev or scratch_dev
     rt_stats stats = {};
     bool stats_pending = false;
     int lds_budget = 39 * 1024;       // per workgroup: 4 workgroups (+ their few static bytes) fit a CU's 160 KiB
@@ -56,6 +59,33 @@ struct rt_context {
 };
 
 static char g_create_err[512] = "";
+
+// ---- rt_render_noalloc's scratch ------------------------------------------------------------------
+// One array per GPU the library runs on, held until the process ends: [0, 256) the RtStatsDev counters,
+// [256, ...) the sample-split plane (one float4 per sample and pixel).  The name `scratch` is a
+// host-side stand-in in host code, not a device address: every use goes through the per-device pointer
+// that hipGetSymbolAddress returned with that device current (scratch_for_device, called by rt_create).
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static_assert(sizeof(RtStatsDev) <= RT_NOALLOC_STATS_BYTES, "the counters must fit the head of the scratch array");
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];      // each GPU holds its own copy of the array at its own address
+static std::mutex g_scratch_mutex;
+
+// The calling thread's current device must be `device`.
+static hipError_t scratch_for_device(int device, void **out)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 static int fail(rt_context *ctx, int code, const char *fmt, ...)
 {
@@ -197,6 +227,7 @@ int rt_create(rt_context **out, int device_id)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->stats_dev, sizeof(RtStatsDev));
+    if (e == hipSuccess) e = scratch_for_device(device_id, &ctx->scratch_dev);     // device_id is current here
     if (e != hipSuccess) {
         fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e));
         rt_destroy(ctx);
@@ -622,7 +653,13 @@ static int ensure_plane(rt_context *ctx, int plane, size_t bytes)
     return RT_OK;
 }
 
-int rt_render_async(rt_context *ctx, const rt_render_params *p)
+// Caller-owned output planes of rt_render_noalloc; NULL = the allocating path of rt_render_async.
+struct NoAllocPlanes {
+    void *plane[2];       // [0] rgba8, [1] f32x4
+    size_t bytes[2];
+};
+
+static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAllocPlanes *na)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: params NULL");
@@ -666,13 +703,19 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)out_width * (size_t)(y1 - y0);
     ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
-    if (outputs & RT_OUT_RGBA8) {
-        int rc = ensure_plane(ctx, 0, px * 4 ? px * 4 : 4);
-        if (rc) return rc;
-    }
-    if (outputs & RT_OUT_F32X4) {
-        int rc = ensure_plane(ctx, 1, px * 16 ? px * 16 : 16);
-        if (rc) return rc;
+    for (int i = 0; i < 2; i++) {
+        if (!(outputs & (i ? RT_OUT_F32X4 : RT_OUT_RGBA8))) continue;
+        const size_t need = px * (i ? 16 : 4);
+        if (na) {
+            if (!na->plane[i] || ((uintptr_t)na->plane[i] & 15))
+                return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: output plane %d is NULL or not 16-byte aligned", i);
+            if (na->bytes[i] < need)
+                return fail(ctx, RT_ERR_BUFFER_TOO_SMALL, "rt_render_noalloc: output plane %d holds %zu bytes, render needs %zu", i, na->bytes[i], need);
+            ctx->cur_plane[i] = na->plane[i];
+        } else {
+            int rc = ensure_plane(ctx, i, need ? need : (i ? 16 : 4));
+            if (rc) return rc;
+        }
     }
 
     RtFrameDev fr = {};
@@ -725,8 +768,19 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     // traffic (32 B per sample and pixel) on scenes whose sweeps are long (rt_sweep_can_split_samples);
     // capped at 1 GiB.
     const size_t split_bytes = px * (size_t)p->spp * sizeof(float4);
-    if (ctx->sample_split && !fr.lane_samples && !ctx->simple_kernel && px > 0 && split_bytes <= ((size_t)1 << 30) &&
-        rt_sweep_can_split_samples(use_scene, fr, grouped)) {
+    const bool want_split = ctx->sample_split && !fr.lane_samples && !ctx->simple_kernel && px > 0 &&
+                            rt_sweep_can_split_samples(use_scene, fr, grouped);
+    if (na) {
+        // the sample-split plane lives in this device's scratch array behind the counters; a render whose
+        // plane does not fit is rejected (the allocating path would grow its buffer instead)
+        const size_t room = (size_t)RT_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_STATS_BYTES;
+        if (want_split) {
+            if (split_bytes > room)
+                return fail(ctx, RT_ERR_LIMIT, "rt_render_noalloc: %zu pixels x %d samples need %zu bytes of scratch, the fixed array holds %zu "
+                            "(render fewer rows per call, or use rt_render)", px, p->spp, split_bytes, room);
+            fr.sample_buf = (float4 *)((unsigned char *)ctx->scratch_dev + RT_NOALLOC_STATS_BYTES);
+        }
+    } else if (want_split && split_bytes <= ((size_t)1 << 30)) {
         if (ctx->sample_bytes < split_bytes) {
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->sample_buf) RT_HIP(ctx, hipFree(ctx->sample_buf));
@@ -745,9 +799,18 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
 
     RtStatsDev *sdev = nullptr;
     if (p->collect_stats) {
-        sdev = ctx->stats_dev;
+        // (the scratch array keeps the last call's counters: they start from zero every time)
+        sdev = na ? (RtStatsDev *)ctx->scratch_dev : ctx->stats_dev;
         RT_HIP(ctx, hipMemsetAsync(sdev, 0, sizeof(RtStatsDev), ctx->stream));
     }
+    if (na) {
+        // no events here: creating one allocates, and nothing may; kernel_ms keeps its last value
+        if (px > 0) {
+            RT_HIP(ctx, rt_launch_trace_sweep(grouped ? ctx->scene_grouped : ctx->scene, ctx->cam, fr, smp, sdev,
+                                              p->mode == RT_MODE_FAST, grouped, ctx->stream));
+            if (fr.sample_buf) RT_HIP(ctx, rt_launch_resolve_samples(fr, ctx->stream));
+        }
+    } else {
     if (ctx->ev_pending.size() >= 256) {          // bound the pool: fold the oldest launches in
         int rc = drain_events(ctx, false);
         if (rc) return rc;
@@ -769,7 +832,9 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     }
     RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     ctx->ev_pending.emplace_back(ev0, ev1);
+    }
 
+    ctx->stats_src = sdev;
     ctx->frame = fr;
     ctx->have_frame = true;
     ctx->last_outputs = outputs & (RT_OUT_RGBA8 | RT_OUT_F32X4);
@@ -779,6 +844,17 @@ int rt_render_async(rt_context *ctx, const rt_render_params *p)
     ctx->stats.n_objects = (uint64_t)ctx->scene.n_objects;
     ctx->stats.n_emitters = (uint64_t)ctx->scene.n_emit;
     return RT_OK;
+}
+
+int rt_render_async(rt_context *ctx, const rt_render_params *p) { return render_impl(ctx, p, nullptr); }
+
+int rt_render_noalloc(rt_context *ctx, const rt_render_params *p, void *rgba8_dev, size_t rgba8_bytes, void *f32x4_dev,
+                      size_t f32x4_bytes)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->simple_kernel) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: not with the transcription kernel (RT_AMD_KERNEL=simple)");
+    const NoAllocPlanes na = {{rgba8_dev, f32x4_dev}, {rgba8_bytes, f32x4_bytes}};
+    return render_impl(ctx, p, &na);
 }
 
 int rt_sync(rt_context *ctx)
@@ -907,7 +983,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
     ctx->stats.kernels_timed = ctx->kernels_timed;
     if (ctx->stats_pending) {
         RtStatsDev h;
-        RT_HIP(ctx, hipMemcpy(&h, ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost));
+        RT_HIP(ctx, hipMemcpy(&h, ctx->stats_src ? ctx->stats_src : ctx->stats_dev, sizeof h, hipMemcpyDeviceToHost));
         ctx->stats.reflection_rays = h.reflection;
         ctx->stats.shadow_rays = h.shadow;
         ctx->stats.hits = h.hits;
