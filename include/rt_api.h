@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 1
+#define RT_API_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -288,11 +288,14 @@ int rt_bmp_header(int32_t width, int32_t height, uint8_t out[54]);
 
 /* Introspection, host only (no device needed): the grouping rt_upload_scene builds for
  * RT_SWEEP_GROUPED.  No counterpart in the reference.  group_bounds / super_bounds receive 4 floats per
- * group / super-group (centre, radius of the bounding sphere); group_of_object receives, per object,
+ * group / super-group: centre g and radius R of the bound {x : |diag(sigma)(x - g)| <= R}, an ellipsoid
+ * whose per-scene shape `sigma` (may be NULL) is 1 along the axis the groups are widest in and 2 or 4 along
+ * axes they are thin in -- (1,1,1), plain bounding spheres, for scenes without such an axis;
+ * group_of_object receives, per object,
  * the index of its group or -1 for a plane; super-group s holds groups [8s, 8s + 8).  Returns
  * RT_ERR_BUFFER_TOO_SMALL (with the counts filled in) when max_groups is too small. */
 int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t *n_groups, int32_t *n_supers,
-                   float *group_bounds, float *super_bounds, int32_t *group_of_object);
+                   float *group_bounds, float *super_bounds, int32_t *group_of_object, float sigma[3]);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ def _load():
     lib.rt_interleaved_index.argtypes = [i32, i32, i32]
     lib.rt_interleaved_index.restype = i32
     lib.rt_plan_groups.argtypes = [C.POINTER(Object), i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float),
-                                   C.POINTER(C.c_float), C.POINTER(i32)]
+                                   C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float)]
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
     lib.rt_sync.argtypes = [vp]
@@ -342,7 +342,7 @@ def interleaved_count(width, n, phase):
     return int(lib.rt_interleaved_count(width, n, phase))
 
 
-def plan_groups(objs):
+def plan_groups(objs, with_metric=False):
     """rt_plan_groups: (group bounds [G,4], super-group bounds [S,4], group index per object [n])."""
     n = len(objs)
     cap = n // 1 + 1
@@ -350,10 +350,13 @@ def plan_groups(objs):
     gb = np.zeros((cap, 4), dtype=np.float32)
     sb = np.zeros((cap, 4), dtype=np.float32)
     of = np.zeros(n, dtype=np.int32)
+    sigma = (C.c_float * 3)()
     rc = lib.rt_plan_groups(objs, n, cap, C.byref(ng), C.byref(ns), gb.ctypes.data_as(C.POINTER(C.c_float)),
-                            sb.ctypes.data_as(C.POINTER(C.c_float)), of.ctypes.data_as(C.POINTER(C.c_int32)))
+                            sb.ctypes.data_as(C.POINTER(C.c_float)), of.ctypes.data_as(C.POINTER(C.c_int32)), sigma)
     if rc:
         raise RtError(rc, lib.rt_last_error(None).decode())
+    if with_metric:
+        return gb[:ng.value], sb[:ns.value], of, np.array(list(sigma), dtype=np.float64)
     return gb[:ng.value], sb[:ns.value], of
 
 

@@ -268,6 +268,8 @@ struct GroupedScene {
     std::vector<float4> heads;     // 2 * ceil(n_groups / 2)
     std::vector<float4> supers;    // 2 * ceil(n_supers / 2)
     int n_groups = 0, n_supers = 0;
+    float sigma[3] = {1.0f, 1.0f, 1.0f};   // the metric the bounds are measured in: |x|_S = |diag(sigma) x|, min sigma = 1
+    float kappa = 1.0f;                    // max sigma
 };
 
 static uint32_t spread10(uint32_t v)
@@ -278,6 +280,53 @@ static uint32_t spread10(uint32_t v)
     v = (v | (v << 4)) & 0x030C30C3u;
     v = (v | (v << 2)) & 0x09249249u;
     return v;
+}
+
+// max over the points x of the sphere |x - c| = r of |diag(sig)(x - g)|, v = c - g: how far, in the bounds'
+// norm, a member sphere reaches from the bound's centre.  Maximising sum sig_a^2 (v_a + r n_a)^2 over |n| = 1
+// gives n_a = sig_a^2 v_a r / (lam - sig_a^2 r^2) with lam > kappa^2 r^2 chosen so that |n| = 1 (bisection; |n|
+// decreases in lam); when v has no component along the axes of largest sig and that equation has no root,
+// the rest of n goes along such an axis.  Never more than |S v| + kappa r, the bound used as a safety net.
+static double reach_S(const double v[3], double r, const double sig[3])
+{
+    double sv2 = 0, kap = 0;
+    for (int a = 0; a < 3; a++) { sv2 += sig[a] * sig[a] * v[a] * v[a]; kap = std::max(kap, sig[a]); }
+    const double crude = std::sqrt(sv2) + kap * r;
+    if (!(r > 0) || !std::isfinite(crude) || (sig[0] == sig[1] && sig[1] == sig[2])) return crude;
+    const double top = kap * kap * r * r;
+    auto n_of = [&](double lam, double n[3]) {
+        double nn = 0;
+        for (int a = 0; a < 3; a++) {
+            const double den = lam - sig[a] * sig[a] * r * r;
+            n[a] = den > 0 ? sig[a] * sig[a] * v[a] * r / den : 0.0;
+            nn += n[a] * n[a];
+        }
+        return nn;
+    };
+    double n[3];
+    double lo = top, hi = top + 4.0 * (std::sqrt(sv2) * kap * r + top) + 1e-300;    // |n|(hi) < 1
+    double best = 0;
+    auto value = [&](const double nv[3]) {
+        double t = 0;
+        for (int a = 0; a < 3; a++) t += sig[a] * sig[a] * (v[a] + r * nv[a]) * (v[a] + r * nv[a]);
+        return std::sqrt(t);
+    };
+    for (int it = 0; it < 200; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (n_of(mid, n) > 1.0) lo = mid; else hi = mid;
+    }
+    // candidates: the root (normalised), and the hard case (components off the top axes at lam = top, the rest
+    // along a top axis, either sign)
+    double nn = n_of(hi, n);
+    if (nn > 0) { const double k = 1.0 / std::sqrt(nn); double m[3] = {n[0] * k, n[1] * k, n[2] * k}; best = std::max(best, value(m)); }
+    double h[3] = {0, 0, 0}, hh = 0;
+    for (int a = 0; a < 3; a++)
+        if (sig[a] < kap) { h[a] = sig[a] * sig[a] * v[a] * r / (top - sig[a] * sig[a] * r * r); hh += h[a] * h[a]; }
+    if (hh <= 1.0)
+        for (int a = 0; a < 3; a++)
+            if (sig[a] == kap)
+                for (double sgn : {-1.0, 1.0}) { double m[3] = {h[0], h[1], h[2]}; m[a] = sgn * std::sqrt(1.0 - hh); best = std::max(best, value(m)); }
+    return std::min(crude, best * (1.0 + 1e-9));
 }
 
 static void build_groups(const std::vector<float4> &geom, const std::vector<float> &radius,
@@ -377,6 +426,59 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
     }
     close();
 
+    // The metric of the bounds.  Spheres standing on a floor make groups that are wide and flat; a round
+    // bound of such a group is mostly air above it, and every ray that rises through that air visits the
+    // group for nothing.  So bounds are ELLIPSOIDS with one shape for the whole scene: spheres in the norm
+    // |x|_S = |diag(sigma) x|, sigma_a >= 1 stretching the axes along which the groups are thin (sigma_a ~ 1 /
+    // median extent of a group along a, the widest axis at 1, capped at 4; powers of two so that the scaling is
+    // exact).  Scenes whose groups are round get sigma = 1: plain bounding spheres.
+    {
+        std::vector<double> exts[3];
+        for (const Group &g : groups) {
+            if (!std::isfinite(g.R)) continue;
+            double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t i : g.members) {
+                const double cc[3] = {geom[i].x, geom[i].y, geom[i].z}, r = std::fabs((double)radius[i]);
+                for (int a = 0; a < 3; a++) { blo[a] = std::min(blo[a], cc[a] - r); bhi[a] = std::max(bhi[a], cc[a] + r); }
+            }
+            for (int a = 0; a < 3; a++) exts[a].push_back(bhi[a] - blo[a]);
+        }
+        const size_t cnt = exts[0].size();
+        const double ext[3] = {median(exts[0]), median(exts[1]), median(exts[2])};      // the typical group, not the outliers
+        const double widest = std::max(ext[0], std::max(ext[1], ext[2]));
+        for (int a = 0; a < 3; a++) {
+            double sg = (cnt && ext[a] > 0 && std::isfinite(widest)) ? widest / ext[a] : 1.0;
+            sg = sg >= 3.0 ? 4.0 : sg >= 1.6 ? 2.0 : 1.0;
+            if (getenv("RT_AMD_ROUND_BOUNDS")) sg = 1.0;       // A/B knob
+            out.sigma[a] = (float)sg;
+            out.kappa = std::max(out.kappa, (float)sg);
+        }
+    }
+    const double sig[3] = {out.sigma[0], out.sigma[1], out.sigma[2]};
+    // centre = middle of the members' box; radius = the farthest any member sphere reaches from it in the norm
+    auto bound_S = [&](const std::vector<uint32_t> &m, size_t begin, size_t end, const std::vector<Group> *of_groups, double c[3]) {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        auto each = [&](auto &&fn) {
+            if (of_groups) { for (size_t g = begin; g < end; g++) for (uint32_t i : (*of_groups)[g].members) fn(i); }
+            else { for (uint32_t i : m) fn(i); }
+        };
+        bool ok = true;
+        each([&](uint32_t i) {
+            const double cc[3] = {geom[i].x, geom[i].y, geom[i].z}, r = std::fabs((double)radius[i]);
+            ok = ok && finite[i];
+            for (int a = 0; a < 3; a++) { blo[a] = std::min(blo[a], cc[a] - r); bhi[a] = std::max(bhi[a], cc[a] + r); }
+        });
+        if (!ok) { c[0] = c[1] = c[2] = 0.0; return (double)INFINITY; }
+        for (int a = 0; a < 3; a++) c[a] = 0.5 * (blo[a] + bhi[a]);
+        double R = 0;
+        each([&](uint32_t i) {
+            const double v[3] = {geom[i].x - c[0], geom[i].y - c[1], geom[i].z - c[2]};
+            R = std::max(R, reach_S(v, std::fabs((double)radius[i]), sig));
+        });
+        return R;
+    };
+    for (Group &g : groups) g.R = bound_S(g.members, 0, 0, nullptr, g.c);
+
     out.n_groups = (int)groups.size();
     const float kNoHit = 3.402823466e+38f;
     out.pairs.assign((size_t)2 * RT_GROUP_PAIRS * groups.size(), make_float4(0.0f, 0.0f, kNoHit, kNoHit));
@@ -397,14 +499,14 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
     }
     // bounding spheres, two per record; the centre is rounded to float, so the radius is widened by
     // that displacement and then rounded up
-    auto pack_heads = [](const std::vector<std::array<double, 4>> &b, std::vector<float4> &dst) {
+    auto pack_heads = [&](const std::vector<std::array<double, 4>> &b, std::vector<float4> &dst) {
         dst.assign(2 * ((b.size() + 1) / 2), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         for (size_t g = 0; g < b.size(); g++) {
             float c[3];
             double d2 = 0;
             for (int a = 0; a < 3; a++) {
                 c[a] = (float)b[g][a];
-                d2 += ((double)c[a] - b[g][a]) * ((double)c[a] - b[g][a]);
+                d2 += sig[a] * sig[a] * ((double)c[a] - b[g][a]) * ((double)c[a] - b[g][a]);
             }
             const double Rd = (b[g][3] + std::sqrt(d2)) * (1.0 + 0x1p-20);
             // a NaN or overflowing bound: always visit
@@ -423,22 +525,9 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
     std::vector<std::array<double, 4>> sb(out.n_supers);
     for (int sgi = 0; sgi < out.n_supers; sgi++) {
         const size_t g0 = (size_t)sgi * RT_SUPER_GROUPS, g1 = std::min(groups.size(), g0 + RT_SUPER_GROUPS);
-        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
-        bool ok = true;
-        for (size_t g = g0; g < g1; g++) {
-            ok = ok && std::isfinite(groups[g].R) && std::isfinite(groups[g].c[0] + groups[g].c[1] + groups[g].c[2]);
-            for (int a = 0; a < 3; a++) {
-                blo[a] = std::min(blo[a], groups[g].c[a] - groups[g].R);
-                bhi[a] = std::max(bhi[a], groups[g].c[a] + groups[g].R);
-            }
-        }
-        double c[3], R = 0;
-        for (int a = 0; a < 3; a++) c[a] = ok ? 0.5 * (blo[a] + bhi[a]) : 0.0;
-        for (size_t g = g0; g < g1 && ok; g++) {
-            const double dx = groups[g].c[0] - c[0], dy = groups[g].c[1] - c[1], dz = groups[g].c[2] - c[2];
-            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + groups[g].R);
-        }
-        sb[sgi] = {c[0], c[1], c[2], ok ? R : INFINITY};
+        double c[3];
+        const double R = bound_S(groups[g0].members, g0, g1, &groups, c);     // over the member spheres of all its groups
+        sb[sgi] = {c[0], c[1], c[2], R};
     }
     pack_heads(sb, out.supers);
 }
@@ -574,6 +663,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_pairs = (int32_t)(pairs.size() / 2);
     ctx->scene.heads = ctx->scene.supers = nullptr;
     ctx->scene.n_groups = ctx->scene.n_supers = 0;
+    ctx->scene.metric[0] = ctx->scene.metric[1] = ctx->scene.metric[2] = ctx->scene.slack_scale = 1.0f;
     ctx->scene_grouped = ctx->scene;
     ctx->scene_grouped.pairs = (const float4 *)(base + off_gpairs);
     ctx->scene_grouped.sph_id = (const int32_t *)(base + off_gids);
@@ -582,13 +672,15 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene_grouped.supers = (const float4 *)(base + off_supers);
     ctx->scene_grouped.n_groups = grp.n_groups;
     ctx->scene_grouped.n_supers = grp.n_supers;
+    for (int a = 0; a < 3; a++) ctx->scene_grouped.metric[a] = grp.sigma[a] * grp.sigma[a];
+    ctx->scene_grouped.slack_scale = grp.kappa * grp.kappa;
     ctx->cam = *cam;
     ctx->have_scene = true;
     return RT_OK;
 }
 
 int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t *n_groups, int32_t *n_supers,
-                   float *group_bounds, float *super_bounds, int32_t *group_of_object)
+                   float *group_bounds, float *super_bounds, int32_t *group_of_object, float *sigma)
 {
     if (!objs || n <= 0 || !n_groups || !n_supers) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_plan_groups: NULL argument or n <= 0");
     std::vector<float4> geom;
@@ -605,6 +697,7 @@ int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t
     build_groups(geom, radius, sph_id, grp);
     *n_groups = grp.n_groups;
     *n_supers = grp.n_supers;
+    for (int a = 0; sigma && a < 3; a++) sigma[a] = grp.sigma[a];
     if (grp.n_groups > max_groups)
         return fail(nullptr, RT_ERR_BUFFER_TOO_SMALL, "rt_plan_groups: %d groups, room for %d", grp.n_groups, max_groups);
     auto unpack = [](const std::vector<float4> &rec, int count, float *dst) {

@@ -15,8 +15,11 @@
 // Grouped layout (RT_SWEEP_GROUPED): a second copy of pairs/sph_id in which the spheres are sorted
 // along a Morton curve and cut into GROUPS of at most 8 (4 pair records each, short groups padded
 // with unhittable spheres), plus
-//   heads  float4[2*ceil(n_groups/2)]  bounding spheres of the groups, two per 32-byte record:
-//                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail has R = -1: never passes)
+//   heads  float4[2*ceil(n_groups/2)]  bounds of the groups, two per 32-byte record:
+//                              {gx0,gx1,gy0,gy1} {gz0,gz1,R0,R1} (an odd tail is zeros; the index check drops it).
+//                              A bound is the ball {x : |diag(sigma)(x - g)| <= R}: an ellipsoid whose shape
+//                              (RtSceneDev::metric) the upload picks per scene -- flattened along the axis the
+//                              groups are thin in (spheres on a floor), round when they are not
 //   supers float4[2*ceil(n_supers/2)]  the same one level up: bounding spheres of RT_SUPER_GROUPS
 //                              consecutive groups
 // A ray that passes a group's bounding sphere at a distance skips the group's 8 spheres.  The grouped
@@ -67,6 +70,9 @@ struct RtSceneDev {
     const float4 *heads;  // grouped layout only: bounding spheres of the groups ...
     const float4 *supers; // ... and of the super-groups (RT_SUPER_GROUPS consecutive groups each)
     int32_t n_groups, n_supers;
+    // the bounds are balls of the norm |x|_S = |diag(sigma) x| (ellipsoids, one shape per scene; sigma >= 1):
+    float metric[3];      // sigma_a^2
+    float slack_scale;    // max sigma^2: what a world-space allowance grows by in that norm
 };
 
 struct RtFrameDev {

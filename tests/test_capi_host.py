@@ -22,7 +22,7 @@ def test_exports_match_header(capi):
     for name in declared:
         assert hasattr(capi.lib, name), f"librt_amd.so does not export {name}"
     assert sorted(capi.EXPORTS) == declared
-    assert capi.lib.rt_api_version() == 1
+    assert capi.lib.rt_api_version() == 2
 
 
 def test_no_oracle_in_product():
@@ -117,24 +117,29 @@ def test_ctypes_mirror_matches_the_header(capi, tmp_path):
 
 
 def _grouping_invariants(capi, objs):
-    gb, sb, of = capi.plan_groups(objs)
+    gb, sb, of, sigma = capi.plan_groups(objs, with_metric=True)
     gb64, sb64 = gb.astype(np.float64), sb.astype(np.float64)
+    assert sigma.min() == 1.0 and set(sigma) <= {1.0, 2.0, 4.0}
+    kappa = sigma.max()
+    dirs = np.random.default_rng(5).normal(0, 1, (120, 3))
+    dirs = np.concatenate([dirs / np.linalg.norm(dirs, axis=1, keepdims=True), np.eye(3), -np.eye(3)])
     sph = [k for k, o in enumerate(objs) if o.type == capi.RT_OBJ_SPHERE]
     assert all(of[k] == -1 for k in range(len(objs)) if k not in set(sph))
     counts = np.bincount(of[sph], minlength=len(gb))
     assert counts.min() >= 1 and counts.max() <= 8 and len(sb) == (len(gb) + 7) // 8
-    for k in sph:                        # every sphere lies inside its group's bounding sphere ...
+    for k in sph:                        # every sphere lies inside its group's bound {x : |sigma (x - g)| <= R} ...
         o, g = objs[k], of[k]
         c, r = np.array(list(o.a), dtype=np.float64), abs(float(o.radius))
         if not (np.isfinite(c).all() and np.isfinite(r)):
             assert counts[g] == 1        # a sphere nothing can hit sits in a group of its own
             continue
-        assert np.linalg.norm(c - gb64[g, :3]) + r <= gb64[g, 3] * (1 + 1e-6) or np.isinf(gb64[g, 3])
-    for g in range(len(gb)):             # ... and every group inside its super-group's
-        s = g // 8
-        if np.isfinite(gb64[g]).all() and np.isfinite(sb64[s]).all():
-            assert np.linalg.norm(gb64[g, :3] - sb64[s, :3]) + gb64[g, 3] <= sb64[s, 3] * (1 + 1e-6)
-    return gb, sb, of
+        pts = c + r * dirs               # points of the sphere: random ones and the axis extremes
+        s = g // 8                       # ... and inside its super-group's
+        for b in (gb64[g], sb64[s]):
+            reach = np.linalg.norm(sigma * (pts - b[:3]), axis=1).max()
+            assert reach <= b[3] * (1 + 1e-6) or np.isinf(b[3])
+            assert b[3] <= (np.linalg.norm(sigma * (c - b[:3])) + kappa * r) * (1 + 1e-5) or counts[g] > 1 or b is not gb64[g]
+    return gb, sb, of, sigma
 
 
 def test_grouping_invariants(capi):
@@ -142,12 +147,14 @@ def test_grouping_invariants(capi):
     group of at most 8, bounds that contain their members at both levels, outliers and unhittable
     spheres on their own, planes in no group; and the grouping actually is local."""
     objs, _ = capi.make_scene(capi.RT_SCENE_GRID1K, 64, 64)
-    gb, sb, of = _grouping_invariants(capi, objs)
+    gb, sb, of, sigma = _grouping_invariants(capi, objs)
+    assert list(sigma) == [1.0, 4.0, 1.0]          # spheres on a floor: bounds flattened along y
     assert 129 <= len(gb) <= 160 and np.median(gb[:, 3]) < 4.5    # 2x4 blocks of a 1.5-pitch grid; the 4 lights apart
     lights = [k for k, o in enumerate(objs) if any(o.mat.emissive)]
     assert len(lights) == 4 and all(np.count_nonzero(of == of[k]) <= 2 for k in lights)
     objs16, _ = capi.make_scene(capi.RT_SCENE_GRID16K, 64, 64)
-    gb16, _, _ = _grouping_invariants(capi, objs16)
+    gb16, _, _, sigma16 = _grouping_invariants(capi, objs16)
+    assert sigma16[1] == 4.0 and sigma16[2] == 1.0     # (its groups are 2 x 4 blocks, long in z: x may get 2)
     assert len(gb16) < 2400
     rng = np.random.default_rng(9)
     M, S, P = capi.material, capi.sphere, capi.tiled_plane
@@ -155,7 +162,7 @@ def test_grouping_invariants(capi):
     odd = [S(m, tuple(rng.normal(0, 5, 3)), float(rng.uniform(.1, 1))) for _ in range(333)]
     odd += [S(m, (1e6, 0, 0), 5e5), S(m, (float("nan"), 0, 0), 1.0), S(m, (0, 0, 0), float("inf")), P((0, 0, 0), (0, 1, 0)),
             S(m, (0, 1, 0), 1.0)] + [S(m, (2, 2, 2), 1.0) for _ in range(40)]
-    _grouping_invariants(capi, capi.objects(odd))
+    _grouping_invariants(capi, capi.objects(odd))          # (whatever shape the bounds get, they must contain their members)
     one = capi.objects([P((0, 0, 0), (0, 1, 0))])
     gb0, sb0, of0 = capi.plan_groups(one)
     assert len(gb0) == 0 and len(sb0) == 0 and list(of0) == [-1]
