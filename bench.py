@@ -42,23 +42,87 @@ FLOP_PER_PLANE_TEST = 5
 
 
 def profiled_traffic(path, kernel):
-    """HBM-side bytes per launch from a committed rocprofv3 PMC summary of this same command
-    (tools/pmc_profile.sh): FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's gfx950
-    correction doubles FETCH_SIZE for wide streaming reads -- here most of the traffic is 4-byte
+    """(bytes per launch, scratch bytes of the profiled kernel) from a committed rocprofv3 PMC summary of
+    this same command (tools/pmc_profile.sh): FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's
+    gfx950 correction doubles FETCH_SIZE for wide streaming reads -- here most of the traffic is 4-byte
     private-memory (spill/record) accesses, a width the guide calls uncalibrated, so the uncorrected
-    sum is reported and the note says so.  None when the summary is not there."""
+    sum is reported and the note says so.  (None, None) when the summary is not there."""
     try:
-        rows, on = {}, False
+        rows, on, scratch = {}, False, None
         for line in open(path):
             if line.startswith('"# ') or line.startswith("# "):
-                if "vgpr,agpr" not in line:
+                if "vgpr,agpr" in line:
+                    if on:
+                        scratch = int(line.split("=")[1].split(",")[4])
+                else:
                     on = kernel in line
             elif on and "," in line:
                 k, v = line.split(",")[:2]
                 rows[k] = v
-        return (float(rows["FETCH_SIZE"]) + float(rows["WRITE_SIZE"])) * 1024.0
+        return (float(rows["FETCH_SIZE"]) + float(rows["WRITE_SIZE"])) * 1024.0, scratch
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+def built_scratch_bytes(unit, mangled_args):
+    """Private-segment bytes of a kernel of the library as built (raytracer_amd/kernel_resources.json, written
+    by the Makefile from the code objects' metadata notes)."""
+    try:
+        for k in json.load(open(os.path.join(ROOT, "raytracer_amd", "kernel_resources.json")))[unit]:
+            if mangled_args in k["name"]:
+                return int(k["scratch"])
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
+
+
+def reference_as_written(capi, width, height, depth, spp, kind, threads):
+    """The reference's OWN object code (oracle/_ref/libref_trace_d<depth>.so: raytracer_cpp/main.cpp compiled in
+    the build container, see oracle/Makefile) timed on this host: (1) the program's own case -- InitScene +
+    DrawScene at 1024x768, -a 1, -p 2 (its defaults), timed like main.cpp:246-253; (2) this bench's workload
+    through its TraceRay as written (every object a candidate emitter: O(N^2) tests per hit, by-value
+    shared_ptr copies in FindNearestObject) on a bounded sample of pixels.  Rays are counted as the loop as
+    written casts them: primary + reflection + one shadow ray per (hit, object).  When the library is absent
+    (no /root/reference at build time) the figures SURVEY.md section 6 measured in the build container stand in."""
+    import numpy as np
+    from oracle import oracle_lib
+    ref = oracle_lib.load_ref_trace(depth)
+    if ref is None:
+        return {"kind": "survey", "note": "oracle/_ref not built; SURVEY.md section 6, build container (8 vCPU): default scene 1024x768 "
+                "-a 1: 2581 ms at -p 1, 3199 ms at -p 2 (the program's default), 3583 ms at -p 8 = 9.1 Mrays/s as written at -p 2"}
+    out = {"kind": "reference", "library": "oracle/_ref/libref_trace_d%d.so" % depth}
+    if depth == 5:
+        ref.init_scene()
+        t0 = time.perf_counter()
+        ref.draw_scene(None, 2, 1)
+        dt = time.perf_counter() - t0
+        # rays of that frame as written (tests/golden/trace_pins.json: 6 752 898 TraceRay calls, 3 791 785 hits x 6 objects)
+        rays = 6752898 + 3791785 * 6
+        out["program_default"] = {"ms": dt * 1e3, "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 2,
+                                  "sample": "InitScene + DrawScene verbatim, 1024x768, -a 1, -p 2 (main.cpp:232-248): %d rays as written" % rays}
+    # this workload through TraceRay as written, on random pixels, `threads` threads
+    objs, cam = capi.make_scene(kind, width, height)
+    ref.set_scene(objs, cam, counting=True)
+    rng = np.random.default_rng(1)
+    n = 16
+    total_t, total_rays, total_px = 0.0, 0, 0
+    while total_t < 8.0 and total_px < 65536:
+        px = np.stack([rng.integers(0, width, n), rng.integers(0, height, n)], axis=1).astype(np.float32)
+        sxy = (px[:, None, :] + np.asarray([0.1, 0.2, 0.6, 0.5, 0.8, 0.7, 0.2, 0.8], dtype=np.float32).reshape(4, 2)[None, :spp, :]).reshape(-1, 2)
+        ref.reset_counters()
+        t0 = time.perf_counter()
+        ref.trace_samples(sxy, threads=threads)
+        total_t += time.perf_counter() - t0
+        c = ref.counters()
+        n_obj = len(objs)
+        calls = (c["intersects"] - n_obj * n_obj * c["normals"]) // n_obj
+        total_rays += calls + c["ray_from"]           # TraceRay calls + one shadow ray per (hit, object)
+        total_px += n
+        n = min(4096, n * 2)
+    out["workload_sample"] = {"value": total_rays / total_t / 1e6, "unit": "Mrays/s", "cores": threads,
+                              "sample": "%d random pixels x %d spp of this workload through TraceRay as written: %d rays in %.2f s"
+                                        % (total_px, spp, total_rays, total_t)}
+    return out
 
 
 def cpu_baseline(capi, width, height, depth, spp, kind, offsets=None):
@@ -81,7 +145,9 @@ def cpu_baseline(capi, width, height, depth, spp, kind, offsets=None):
     _, _, st1 = oracle_lib.render(objs1, cam1, p1, threads=1, want_rgb8=True, want_f32=False, want_stats=True)
     dt1 = time.perf_counter() - t1
     rays1 = st1["primary_rays"] + st1["reflection_rays"] + st1["shadow_rays_pruned"]
+    as_written = reference_as_written(capi, width, height, depth, spp, kind, threads)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "reference_as_written": as_written,
             "sample": f"same scene/camera at {lw}x{lh} (1/4 of the pixels), depth {depth}, {spp} spp, "
                       f"{rays} rays in {dt:.2f} s, emitter loop pruned to emissive objects",
             "one_core": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
@@ -301,12 +367,19 @@ def main():
                                  "count over this kernel's time; HBM traffic is the framebuffer only (4 B/px)"},
         }
         if world == 1 and (args.scene, W, H, args.depth, args.spp, args.mode) == ("grid1k", 3840, 2160, 5, 4, "exact"):
-            prof = os.path.join(ROOT, "profiles", "r1", "v5_grouped_grid1k.csv" if grouped else "v4_flat_grid1k.csv")
+            # not measurable from inside this process (PMC counters need rocprofv3 around it): taken from the
+            # committed rocprofv3 summary of this same command, and only while the kernel is the one profiled
+            # (same private-segment size as the build that ships: raytracer_amd/kernel_resources.json)
+            prof = os.path.join(ROOT, "profiles", "r2", "current_headline.csv")
             tag = "trace_sweep_kernel<false, false, false, 6, false, true>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, false>"
-            out["roofline"]["traffic"] = profiled_traffic(prof, tag)
-            out["roofline"]["traffic_note"] = ("bytes per launch at the L2's memory side (FETCH_SIZE + WRITE_SIZE, uncorrected) from "
-                                               + os.path.relpath(prof, ROOT) + "; the frame itself is 33 MB: the rest is private-memory "
-                                               "(register spill + per-segment record) traffic, served by L2 / Infinity Cache")
+            traffic, prof_scratch = profiled_traffic(prof, tag)
+            built = built_scratch_bytes("rt_sweep_grouped" if grouped else "rt_sweep_compact", "ILb0ELb0ELb0ELi6ELb0ELb1E" if grouped else "ILb0ELb1ELb0ELi6ELb0ELb0E")
+            same = traffic is not None and built is not None and prof_scratch == built
+            out["roofline"]["traffic"] = traffic if same else None
+            out["roofline"]["traffic_source"] = (os.path.relpath(prof, ROOT) + ": FETCH_SIZE + WRITE_SIZE per launch (bytes at the L2's memory "
+                                                 "side, uncorrected: mostly 4-byte private-memory accesses, a width the guide calls uncalibrated); "
+                                                 "profiled kernel scratch %s B, built kernel %s B%s" % (prof_scratch, built, "" if same else
+                                                 " -- they differ or one is unknown, so the profiled figure is withheld"))
         if world == 1 and grouped:
             # the same frame through the flat sweep (north_star's every-ray-tests-every-sphere kernel)
             pf = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, sweep=capi.RT_SWEEP_FLAT, **part)

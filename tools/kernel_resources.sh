@@ -25,7 +25,11 @@ for blk in txt.split("- .agpr_count:")[1:]:
     name = re.sub(r"^void \(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*$", "", name)
     rows.append((name, g("vgpr_count"), agpr, g("vgpr_spill_count"), g("sgpr_count"), g("sgpr_spill_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
-print("%-62s %5s %5s %7s %5s %7s %8s %6s" % ("kernel", "vgpr", "agpr", "vspill", "sgpr", "sspill", "scratchB", "ldsB"))
-for r in rows:
-    print("%-62s %5s %5s %7s %5s %7s %8s %6s" % r)
+import os, json
+if os.environ.get("KERNEL_RESOURCES_JSON"):
+    print(json.dumps([dict(zip(("name", "vgpr", "agpr", "vgpr_spill", "sgpr", "sgpr_spill", "scratch", "lds"), r)) for r in rows]))
+else:
+    print("%-62s %5s %5s %7s %5s %7s %8s %6s" % ("kernel", "vgpr", "agpr", "vspill", "sgpr", "sspill", "scratchB", "ldsB"))
+    for r in rows:
+        print("%-62s %5s %5s %7s %5s %7s %8s %6s" % r)
 '
