@@ -11,8 +11,9 @@
  * Conventions
  *   - every call returns RT_OK (0) or a negative rt_status; nothing throws or aborts.
  *   - the library copies what it is handed; the caller keeps ownership of its arrays.
- *   - a context is bound to ONE device (one process per GPU; multi-GPU = one context per rank,
- *     each rendering a row band, see rt_render_params.row_begin/row_end and INTEGRATION.md).
+ *   - a context is bound to ONE device (rt_create) or shares each frame between several
+ *     (rt_create_multi: one process drives them all); the one-process-per-GPU scheme instead gives every
+ *     rank its own context and a row band (rt_render_params.row_begin/row_end).
  *   - a context is not re-entrant; distinct contexts may be used from distinct threads.
  *   - there is NO CPU fallback: without a usable HIP device rt_create fails with RT_ERR_NO_DEVICE.
  */
@@ -162,6 +163,8 @@ typedef struct rt_render_params {
 
 #define RT_STRIP_COLS 8
 
+#define RT_MAX_DEVICES 8
+
 typedef struct rt_stats {
     uint64_t primary_rays;      /* W * rows * spp                                                 */
     uint64_t reflection_rays;   /* recursive TraceRay invocations, main.cpp:108                   */
@@ -180,6 +183,15 @@ typedef struct rt_stats {
     uint64_t group_tests_run;   /* (ray, group) bounding-sphere tests executed (RT_SWEEP_GROUPED)   */
     uint64_t exact_tests_run;   /* (ray, sphere) candidates of the filter that took the reference's
                                    exact test (the accept path of glm::intersectRaySphere and more)  */
+    /* A context over several devices (rt_create_multi): the counters above are sums over the devices,
+     * kernel_ms is the slowest device's (a frame takes as long as its slowest band); per device: */
+    uint32_t n_devices;         /* 0 for a single-device context                                     */
+    int32_t device_id[RT_MAX_DEVICES];
+    int32_t device_row_begin[RT_MAX_DEVICES];   /* the band device i rendered in the last frame ...  */
+    int32_t device_row_end[RT_MAX_DEVICES];
+    double device_kernel_ms[RT_MAX_DEVICES];    /* ... the device time of its trace kernel ...        */
+    double device_gather_ms[RT_MAX_DEVICES];    /* ... and of copying its band into the frame         */
+    double gather_ms;           /* the slowest of those copies                                       */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -188,6 +200,16 @@ typedef struct rt_context rt_context;
  * device); owns the device copies of the scene, the framebuffer planes and one stream. */
 int rt_create(rt_context **out, int device_id);
 void rt_destroy(rt_context *ctx);
+
+/* One context over n_devices HIP devices (1..RT_MAX_DEVICES; an id may repeat: its bands then share that
+ * device).  Replaces the thread fan-out INSIDE DrawScene (main.cpp:193-227: `partitions` threads fill one
+ * shared Bitmap): rt_upload_scene replicates the scene, rt_render cuts the rows into one cost-balanced band per
+ * device (1/16-resolution pre-pass on the first device, rt_split_bands), renders them concurrently and
+ * assembles the frame on device_ids[0] (peer copies over xGMI), which is where rt_download_framebuffer,
+ * rt_pack_framebuffer and rt_framebuffer_device_ptr then find it; rt_get_stats adds per-device kernel and
+ * copy times.  Every other call works as on a single-device context, except rt_render_noalloc and
+ * col_interleave (RT_ERR_INVALID_ARG).  n_devices == 1 is rt_create. */
+int rt_create_multi(rt_context **out, const int *device_ids, int n_devices);
 
 /* Replaces the globals sceneObjects / pCamera (main.cpp:18-19) as filled by InitScene
  * (main.cpp:21-63).  May be called again between renders (camera sweeps). */

@@ -21,6 +21,7 @@ RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
 RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2
 RT_STRIP_COLS = 8
+RT_MAX_DEVICES = 8
 RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
 
 
@@ -59,11 +60,14 @@ class Stats(C.Structure):
                 ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                  "sphere_tests", "plane_tests", "n_objects", "n_emitters")] + \
                [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("kernels_timed", C.c_uint64),
-                ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64), ("exact_tests_run", C.c_uint64)]
+                ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64), ("exact_tests_run", C.c_uint64),
+                ("n_devices", C.c_uint32), ("device_id", C.c_int32 * RT_MAX_DEVICES), ("device_row_begin", C.c_int32 * RT_MAX_DEVICES),
+                ("device_row_end", C.c_int32 * RT_MAX_DEVICES), ("device_kernel_ms", C.c_double * RT_MAX_DEVICES),
+                ("device_gather_ms", C.c_double * RT_MAX_DEVICES), ("gather_ms", C.c_double)]
 
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_plan_groups", "rt_interleaved_count", "rt_interleaved_index", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
+    "rt_create", "rt_create_multi", "rt_destroy", "rt_plan_groups", "rt_interleaved_count", "rt_interleaved_index", "rt_upload_scene", "rt_set_camera", "rt_render", "rt_download_framebuffer",
     "rt_pack_framebuffer", "rt_framebuffer_device_ptr", "rt_bind_framebuffer", "rt_get_stream", "rt_set_stream", "rt_render_async",
     "rt_sync", "rt_render_noalloc", "rt_get_stats", "rt_last_error", "rt_api_version", "rt_camera_init",
     "rt_make_scene", "rt_split_bands", "rt_write_bmp", "rt_bmp_header",
@@ -78,6 +82,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float)
     lib.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.rt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
     lib.rt_destroy.argtypes = [vp]
     lib.rt_destroy.restype = None
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Object), i32, C.POINTER(Camera)]
@@ -226,9 +231,14 @@ def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, ou
 class Context:
     """rt_context: one device, one stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """devices: a list of HIP device ids -> one context over all of them (rt_create_multi)."""
         self._h = C.c_void_p()
-        rc = lib.rt_create(C.byref(self._h), device)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            rc = lib.rt_create_multi(C.byref(self._h), ids, len(devices))
+        else:
+            rc = lib.rt_create(C.byref(self._h), device)
         if rc:
             raise RtError(rc, lib.rt_last_error(None).decode())
 
@@ -301,7 +311,7 @@ class Context:
     def stats(self):
         st = Stats()
         self._check(lib.rt_get_stats(self._h, C.byref(st)))
-        return {n: getattr(st, n) for n, _ in Stats._fields_}
+        return {n: (list(getattr(st, n)) if hasattr(getattr(st, n), "__len__") else getattr(st, n)) for n, _ in Stats._fields_}
 
 
 # ---- scene construction helpers mirroring the reference's constructors -------------------------

@@ -54,6 +54,17 @@ struct rt_context {
     const RtStatsDev *stats_src = nullptr;   // where the last render's counters are: stats_dev or scratch_dev
     rt_stats stats = {};
     bool stats_pending = false;
+    // ---- a context over several devices (rt_create_multi): this root object holds the assembled frame on
+    // parts[0]'s device and one single-device context per entry of device_ids
+    std::vector<rt_context *> parts;
+    std::vector<int32_t> bounds;      // row bands of the last plan: part i renders [bounds[i], bounds[i+1])
+    struct PlanKey { int32_t w, h, depth, y0, y1, spp, sweep; uint64_t scene_version; } plan_key = {};
+    bool have_plan = false;
+    uint64_t scene_version = 0;       // bumped by rt_upload_scene / rt_set_camera
+    std::vector<hipEvent_t> part_done, copy_begin;   // per part: band copied into the frame; its copy began
+    hipEvent_t root_ready = nullptr;  // the root stream's work before a render (the caller's, on its stream)
+    double gather_ms_last = 0.0;
+    bool gather_pending = false;
     int lds_budget = 39 * 1024;       // per workgroup: 4 workgroups (+ their few static bytes) fit a CU's 160 KiB
     bool simple_kernel = false;       // RT_AMD_KERNEL=simple: the straight-transcription kernel (A/B)
 };
@@ -237,9 +248,60 @@ int rt_create(rt_context **out, int device_id)
     return RT_OK;
 }
 
+int rt_create_multi(rt_context **out, const int *device_ids, int n_devices)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create_multi: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > RT_MAX_DEVICES)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create_multi: device_ids NULL or n_devices outside [1,%d]", RT_MAX_DEVICES);
+    if (n_devices == 1) return rt_create(out, device_ids[0]);
+    rt_context *root = nullptr;
+    int rc = rt_create(&root, device_ids[0]);          // owns the assembled frame and the stream callers order against
+    if (rc) return rc;
+    for (int i = 0; i < n_devices && rc == RT_OK; i++) {
+        rt_context *part = nullptr;
+        rc = rt_create(&part, device_ids[i]);          // the same device may appear more than once: its bands then share it
+        if (rc == RT_OK) root->parts.push_back(part);
+    }
+    if (rc == RT_OK) {
+        // a band's way into the frame: peer access where the devices differ (hipMemcpyPeerAsync falls back to
+        // staging through the host when it cannot be had)
+        for (int i = 0; i < n_devices; i++) {
+            if (device_ids[i] == device_ids[0]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
+                (void)hipSetDevice(device_ids[0]);
+                hipError_t e = hipDeviceEnablePeerAccess(device_ids[i], 0);
+                if (e != hipSuccess) (void)hipGetLastError();       // already enabled
+            }
+        }
+        hipError_t e = hipSetDevice(device_ids[0]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&root->root_ready, hipEventDisableTiming);
+        for (int i = 0; i < n_devices && e == hipSuccess; i++) {
+            hipEvent_t a = nullptr, b = nullptr;
+            e = hipSetDevice(device_ids[i]);
+            if (e == hipSuccess) e = hipEventCreate(&a);
+            if (e == hipSuccess) e = hipEventCreate(&b);
+            root->copy_begin.push_back(a);
+            root->part_done.push_back(b);
+        }
+        if (e != hipSuccess) rc = fail(nullptr, RT_ERR_HIP, "rt_create_multi: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        rt_destroy(root);
+        return rc;
+    }
+    *out = root;
+    return RT_OK;
+}
+
 void rt_destroy(rt_context *ctx)
 {
     if (!ctx) return;
+    for (rt_context *part : ctx->parts) rt_destroy(part);
+    for (hipEvent_t e : ctx->part_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->copy_begin) if (e) (void)hipEventDestroy(e);
+    if (ctx->root_ready) (void)hipEventDestroy(ctx->root_ready);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scene_blob) (void)hipFree(ctx->scene_blob);
@@ -537,6 +599,16 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!objs || n <= 0 || !cam) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: objs/cam NULL or n <= 0");
     if (n > (1 << 22)) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %d objects > limit %d", n, 1 << 22);
+    ctx->scene_version++;
+    for (rt_context *part : ctx->parts) {              // a context over several devices: the scene is replicated
+        int rc = rt_upload_scene(part, objs, n, cam);
+        if (rc) return fail(ctx, rc, "device %d: %s", part->device, part->err);
+    }
+    if (!ctx->parts.empty()) {
+        ctx->cam = *cam;
+        ctx->have_scene = true;
+        return RT_OK;
+    }
 
     std::vector<float4> geom;
     std::vector<float> radius;
@@ -722,6 +794,8 @@ int rt_set_camera(rt_context *ctx, const rt_camera *cam)
     if (!cam) return fail(ctx, RT_ERR_INVALID_ARG, "rt_set_camera: cam NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_set_camera: no scene uploaded");
     ctx->cam = *cam;          // passed by value with every launch: nothing on the device changes
+    ctx->scene_version++;
+    for (rt_context *part : ctx->parts) part->cam = *cam;
     return RT_OK;
 }
 
@@ -752,9 +826,156 @@ struct NoAllocPlanes {
     size_t bytes[2];
 };
 
+// ---- one frame over several devices (rt_create_multi) --------------------------------------------------
+// The reference parallelises INSIDE DrawScene: its rows are dealt to `partitions` threads that fill one shared
+// Bitmap (main.cpp:193-227).  Here the rows [y0, y1) are cut into one contiguous band per device, balanced by a
+// cost map from a 1/16-resolution pre-pass on the first device (per pixel: the tests its rays executed, exact
+// tests weighted 32x, 300 per ray -- RT_OUT_COST); every device renders its band on its own stream into planes
+// of its own, and the bands are copied into the frame on the first device (hipMemcpyPeerAsync over xGMI; a plain
+// device copy where a band's device is the frame's).  The root context's stream waits for every copy, so the
+// download / pack / caller's work that follows on it sees the whole frame.
+static int plan_bands_multi(rt_context *ctx, const rt_render_params *p, int y0, int y1)
+{
+    const int n = (int)ctx->parts.size();
+    rt_context *first = ctx->parts[0];
+    const int lw = (p->width + 3) / 4, lh = (p->height + 3) / 4;
+    rt_render_params q = {};
+    q.width = lw;
+    q.height = lh;
+    q.max_depth = p->max_depth;
+    q.spp = 1;
+    q.outputs = RT_OUT_F32X4 | RT_OUT_COST;
+    q.collect_stats = 1;
+    q.mode = p->mode;
+    q.sweep = p->sweep;
+    const rt_camera full = first->cam;
+    rt_camera low = full;                                // same pose and lens, smaller view plane (camera.h:24-25,41)
+    low.image_width = (float)lw;
+    low.image_height = (float)lh;
+    low.aspect_ratio = (float)lw / (float)lh;
+    first->cam = low;
+    void *keep[2] = {first->bound_plane[0], first->bound_plane[1]};
+    first->bound_plane[0] = first->bound_plane[1] = nullptr;
+    int rc = rt_render(first, &q);
+    std::vector<float> plane((size_t)lw * (size_t)lh * 4);
+    if (rc == RT_OK) rc = rt_download_framebuffer(first, plane.data(), plane.size() * sizeof(float), RT_FMT_F32X4);
+    first->cam = full;
+    first->bound_plane[0] = keep[0];
+    first->bound_plane[1] = keep[1];
+    if (rc) return fail(ctx, rc, "pre-pass on device %d: %s", first->device, first->err);
+    std::vector<double> low_cost((size_t)lh, 0.0);
+    for (int r = 0; r < lh; r++)
+        for (int c = 0; c < lw; c++) low_cost[(size_t)r] += (double)plane[((size_t)r * (size_t)lw + (size_t)c) * 4 + 3];
+    std::vector<float> cost((size_t)(y1 - y0));
+    for (int y = y0; y < y1; y++) {
+        const long long r = std::min<long long>(((long long)y * lh) / p->height, lh - 1);
+        const double c = low_cost[(size_t)r];
+        cost[(size_t)(y - y0)] = (c >= 0.0 && c < 3.0e38) ? (float)c : 0.0f;
+    }
+    std::vector<int32_t> b((size_t)n + 1);
+    rc = rt_split_bands(cost.data(), y1 - y0, n, b.data());
+    if (rc) return fail(ctx, rc, "rt_split_bands failed on the pre-pass cost map");
+    ctx->bounds.resize((size_t)n + 1);
+    for (int i = 0; i <= n; i++) ctx->bounds[(size_t)i] = y0 + b[(size_t)i];
+    return RT_OK;
+}
+
+static int render_impl(rt_context *ctx, const rt_render_params *p, const struct NoAllocPlanes *na);
+
+static int render_multi(rt_context *ctx, const rt_render_params *p)
+{
+    if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: params NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+    if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad image size %dx%d", p->width, p->height);
+    if (p->col_interleave > 1)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: a context over several devices shares the rows itself; col_interleave is for one context per device");
+    int y0 = p->row_begin, y1 = p->row_end;
+    if (y0 == 0 && y1 == 0) y1 = p->height;
+    if (y0 < 0 || y1 > p->height || y0 > y1)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad row range [%d,%d) for height %d", y0, y1, p->height);
+    const int n = (int)ctx->parts.size();
+    int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
+
+    // 1. the plan: kept while scene, camera and frame geometry stay (and for the whole of a progressive
+    //    accumulation, whose running mean lives in each device's band)
+    const rt_context::PlanKey key = {p->width, p->height, p->max_depth, y0, y1, p->spp, p->sweep, ctx->scene_version};
+    const bool continuing = p->accumulate && p->accum_index > 0 && ctx->have_plan && ctx->plan_key.w == key.w &&
+                            ctx->plan_key.h == key.h && ctx->plan_key.y0 == key.y0 && ctx->plan_key.y1 == key.y1;
+    if (!continuing && !(ctx->have_plan && memcmp(&key, &ctx->plan_key, sizeof key) == 0)) {
+        ctx->have_plan = false;
+        int rc = plan_bands_multi(ctx, p, y0, y1);
+        if (rc) return rc;
+        memset(&ctx->plan_key, 0, sizeof ctx->plan_key);
+        ctx->plan_key = key;
+        ctx->have_plan = true;
+    }
+
+    // 2. the frame on the first device
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)p->width * (size_t)(y1 - y0);
+    ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (!(outputs & (i ? RT_OUT_F32X4 : RT_OUT_RGBA8))) continue;
+        const size_t need = px * (i ? 16 : 4);
+        int rc = ensure_plane(ctx, i, need ? need : 16);
+        if (rc) return rc;
+    }
+
+    // 3. bands: each device renders on its own stream, after whatever is already on the root's
+    RT_HIP(ctx, hipEventRecord(ctx->root_ready, ctx->stream));
+    for (int i = 0; i < n; i++) {
+        rt_context *part = ctx->parts[(size_t)i];
+        const int b0 = ctx->bounds[(size_t)i], b1 = ctx->bounds[(size_t)i + 1];
+        RT_HIP(ctx, hipSetDevice(part->device));
+        RT_HIP(ctx, hipStreamWaitEvent(part->stream, ctx->root_ready, 0));
+        RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));     // (an empty band: begin == done)
+        if (b1 > b0) {
+            rt_render_params q = *p;
+            q.row_begin = b0;
+            q.row_end = b1;
+            q.first_row = (p->first_row > b0 && p->first_row < b1) ? p->first_row : 0;
+            int rc = render_impl(part, &q, nullptr);
+            if (rc) return fail(ctx, rc, "device %d, rows [%d,%d): %s", part->device, b0, b1, part->err);
+            RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));
+            for (int k = 0; k < 2; k++) {
+                if (!ctx->cur_plane[k]) continue;
+                const size_t bpp = k ? 16 : 4, bytes = (size_t)p->width * (size_t)(b1 - b0) * bpp;
+                char *dst = (char *)ctx->cur_plane[k] + (size_t)p->width * (size_t)(b0 - y0) * bpp;
+                if (part->device == ctx->device)
+                    RT_HIP(ctx, hipMemcpyAsync(dst, part->cur_plane[k], bytes, hipMemcpyDeviceToDevice, part->stream));
+                else
+                    RT_HIP(ctx, hipMemcpyPeerAsync(dst, ctx->device, part->cur_plane[k], part->device, bytes, part->stream));
+            }
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->part_done[(size_t)i], part->stream));
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->part_done[(size_t)i], 0));
+
+    RtFrameDev fr = {};
+    fr.rgba8 = (uint32_t *)ctx->cur_plane[0];
+    fr.f32x4 = (float4 *)ctx->cur_plane[1];
+    fr.width = p->width;
+    fr.height = p->height;
+    fr.row_begin = y0;
+    fr.row_end = y1;
+    fr.spp = p->spp;
+    ctx->frame = fr;
+    ctx->have_frame = true;
+    ctx->last_outputs = outputs & (RT_OUT_RGBA8 | RT_OUT_F32X4);
+    ctx->stats_pending = p->collect_stats != 0;
+    ctx->gather_pending = true;
+    return RT_OK;
+}
+
 static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAllocPlanes *na)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!ctx->parts.empty()) {
+        if (na) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: not on a context over several devices (its frame assembly allocates)");
+        return render_multi(ctx, p);
+    }
     if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: params NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
     if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536)
@@ -953,6 +1174,10 @@ int rt_render_noalloc(rt_context *ctx, const rt_render_params *p, void *rgba8_de
 int rt_sync(rt_context *ctx)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
+    for (rt_context *part : ctx->parts) {
+        int rc = rt_sync(part);
+        if (rc) return fail(ctx, rc, "device %d: %s", part->device, part->err);
+    }
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
@@ -1068,6 +1293,49 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
 {
     if (!ctx || !out) return RT_ERR_INVALID_ARG;
     if (!ctx->have_frame) return fail(ctx, RT_ERR_NO_FRAME, "rt_get_stats: nothing rendered yet");
+    if (!ctx->parts.empty()) {
+        // over several devices: counters add up, times are per device; the frame took as long as its slowest band
+        int rc = rt_sync(ctx);
+        if (rc) return rc;
+        rt_stats total = {};
+        total.n_devices = (uint32_t)ctx->parts.size();
+        for (size_t i = 0; i < ctx->parts.size(); i++) {
+            rt_context *part = ctx->parts[i];
+            total.device_id[i] = part->device;
+            total.device_row_begin[i] = ctx->bounds[i];
+            total.device_row_end[i] = ctx->bounds[i + 1];
+            if (ctx->bounds[i + 1] == ctx->bounds[i]) continue;            // an empty band rendered nothing
+            rt_stats st = {};
+            if ((rc = rt_get_stats(part, &st))) return fail(ctx, rc, "device %d: %s", part->device, part->err);
+            total.primary_rays += st.primary_rays;
+            total.reflection_rays += st.reflection_rays;
+            total.shadow_rays += st.shadow_rays;
+            total.hits += st.hits;
+            total.lit += st.lit;
+            total.sphere_tests += st.sphere_tests;
+            total.plane_tests += st.plane_tests;
+            total.sphere_tests_run += st.sphere_tests_run;
+            total.group_tests_run += st.group_tests_run;
+            total.exact_tests_run += st.exact_tests_run;
+            total.n_objects = st.n_objects;
+            total.n_emitters = st.n_emitters;
+            total.device_kernel_ms[i] = st.kernel_ms;
+            total.kernel_ms = std::max(total.kernel_ms, st.kernel_ms);
+            total.kernel_ms_total = std::max(total.kernel_ms_total, st.kernel_ms_total);
+            total.kernels_timed = std::max(total.kernels_timed, st.kernels_timed);
+            if (ctx->gather_pending) {
+                float ms = 0.0f;
+                RT_HIP(ctx, hipSetDevice(part->device));
+                RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->copy_begin[i], ctx->part_done[i]));
+                total.device_gather_ms[i] = (double)ms;
+                total.gather_ms = std::max(total.gather_ms, (double)ms);
+            }
+        }
+        if (!ctx->gather_pending) total.gather_ms = ctx->gather_ms_last;
+        ctx->gather_ms_last = total.gather_ms;
+        *out = total;
+        return RT_OK;
+    }
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     { int rc = drain_events(ctx, true); if (rc) return rc; }

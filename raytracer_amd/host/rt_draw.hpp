@@ -26,6 +26,8 @@ struct DrawSceneError : std::runtime_error {
 struct DrawSceneOptions {
     int maxDepth = 5;           // MAX_DEPTH, main.cpp:16
     int device = 0;
+    std::vector<int> devices;   // more than one entry: the frame is shared between these HIP devices (rt_create_multi),
+                                // the counterpart of the reference's thread fan-out inside DrawScene (main.cpp:193-227)
     int mode = RT_MODE_EXACT;   // RT_MODE_FAST: radiance to rounding instead of bit-identical
     int sweep = RT_SWEEP_AUTO;  // RT_SWEEP_FLAT / RT_SWEEP_GROUPED: same image either way
     double *kernelMs = nullptr; // optional: device time of the trace kernel (summed over frames)
@@ -48,8 +50,9 @@ inline float lcg_unit(uint32_t &s)
 }
 } // namespace rt_detail
 
-// `partitions` is the reference's CPU thread count; the device schedules its own waves, so the
-// value only has to be positive.  `antialias` selects the reference's 4 fixed sub-pixel samples.
+// `partitions` is the reference's CPU thread count; a device schedules its own waves, so the
+// value only has to be positive.  The parallelism the reference has inside this call -- rows dealt to threads
+// -- is DrawSceneOptions::devices here: rows dealt to GPUs.  `antialias` selects the reference's 4 fixed sub-pixel samples.
 inline void DrawScene(Bitmap *pBitmap, int partitions, bool antialias, const DrawSceneOptions &opt = DrawSceneOptions())
 {
     if (!pBitmap || partitions < 1 || !pCamera || sceneObjects.empty())
@@ -59,7 +62,8 @@ inline void DrawScene(Bitmap *pBitmap, int partitions, bool antialias, const Dra
     const rt_camera cam = pCamera->Flatten();
 
     rt_context *ctx = nullptr;
-    int rc = rt_create(&ctx, opt.device);
+    int rc = opt.devices.size() > 1 ? rt_create_multi(&ctx, opt.devices.data(), (int)opt.devices.size())
+                                    : rt_create(&ctx, opt.devices.size() == 1 ? opt.devices[0] : opt.device);
     if (rc != RT_OK) throw DrawSceneError(rc, rt_last_error(nullptr));
     auto fail = [&](int code) {
         const std::string msg = rt_last_error(ctx);

@@ -2,8 +2,11 @@
 // MI355X library.  Same options (-p/--partitions, -a/--antialiased), same scene, same "Time:" line,
 // same image.bmp.  Extra options select the size, depth, device, output path, a scene file
 // (rt_scenefile.hpp) instead of InitScene's scene, and the library's mode / sweep.
+#include <algorithm>
 #include <chrono>
 #include <iostream>
+#include <stdexcept>
+#include <string>
 
 #include "rt_cmdline.hpp"
 #include "rt_draw.hpp"
@@ -43,7 +46,7 @@ int main(int argc, char **argv)
     parser.set_optional<int>("W", "width", 1024, "image width");
     parser.set_optional<int>("H", "height", 768, "image height");
     parser.set_optional<int>("d", "depth", 5, "MAX_DEPTH");
-    parser.set_optional<int>("g", "gpu", 0, "HIP device");
+    parser.set_optional<std::string>("g", "gpu", "0", "HIP device, or a comma-separated list: the frame is shared between them");
     parser.set_optional<std::string>("o", "output", "image.bmp", "BMP file to write");
     parser.set_optional<std::string>("s", "scene", "", "scene description file (default: the reference's InitScene scene)");
     parser.set_optional<int>("f", "frames", 1, "progressive mode: this many jittered single-sample frames, running mean");
@@ -75,7 +78,24 @@ int main(int argc, char **argv)
 
     DrawSceneOptions opt;
     opt.maxDepth = parser.get<int>("d");
-    opt.device = parser.get<int>("g");
+    {
+        const std::string list = parser.get<std::string>("g");
+        size_t at = 0;
+        try {
+            while (at <= list.size()) {
+                const size_t comma = std::min(list.find(',', at), list.size());
+                size_t used = 0;
+                const std::string item = list.substr(at, comma - at);
+                opt.devices.push_back(std::stoi(item, &used));
+                if (used != item.size() || opt.devices.back() < 0) throw std::invalid_argument(item);
+                at = comma + 1;
+            }
+        } catch (const std::exception &) {
+            std::cerr << "-g wants a device index or a comma-separated list of them, got '" << list << "'" << std::endl;
+            DestroyBitmap(pBitmap);
+            return 2;
+        }
+    }
     opt.frames = parser.get<int>("f");
     opt.lensRadius = parser.get<float>("l");
     opt.focalLength = parser.get<float>("F");

@@ -556,3 +556,63 @@ def test_camera_sweep_pipeline(capi, oracle, gpu_ctx, tmp_path):
     # the context is usable again afterwards, with the last camera still set
     gpu_ctx.render(capi.render_params(w, h, 5, 1))
     assert np.array_equal(gpu_ctx.download(capi.RT_FMT_RGB8, w, h), got[100 + n - 1])
+
+
+@pytest.mark.parametrize("scene,size,depth,spp,n", [("grid1k", (1000, 613), 5, 4, 2), ("grid1k", (640, 360), 8, 1, 5),
+                                                    ("default", (323, 200), 5, 4, 8), ("grid1k", (96, 3), 5, 1, 8)])
+def test_multi_device_context(capi, gpu_ctx, scene, size, depth, spp, n):
+    """rt_create_multi with the same device listed n times (n streams on one GPU: SURVEY.md 4, item 5): the
+    assembled frame -- radiance bits, per-pixel ray counts, 8-bit image -- and the ray counters equal the
+    single-device context's; the bands tile the rows; per-device times are reported; and the plan is kept
+    between renders of the same view."""
+    w, h = size
+    kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K}[scene]
+    objs, cam = capi.make_scene(kind, w, h)
+    gpu_ctx.upload_scene(objs, cam)
+    p = capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, stats=True)
+    gpu_ctx.render(p)
+    want = gpu_ctx.download(capi.RT_FMT_RGB8, w, h), gpu_ctx.download(capi.RT_FMT_F32X4, w, h), gpu_ctx.stats()
+    multi = capi.Context(devices=[0] * n)
+    try:
+        multi.upload_scene(objs, cam)
+        for _ in range(2):
+            multi.render(p)
+            assert np.array_equal(multi.download(capi.RT_FMT_RGB8, w, h), want[0])
+            assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), want[1].view(np.uint32))
+            st = multi.stats()
+            for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit"):      # (tests executed depend on how rows fall into waves)
+                assert st[k] == want[2][k], k
+            assert st["n_devices"] == n and st["device_id"][:n] == [0] * n
+            b0, b1 = st["device_row_begin"][:n], st["device_row_end"][:n]
+            assert b0[0] == 0 and b1[-1] == h and all(b1[i] == b0[i + 1] for i in range(n - 1)) and all(b1[i] >= b0[i] for i in range(n))
+            assert st["kernel_ms"] == max(st["device_kernel_ms"][:n]) and st["gather_ms"] == max(st["device_gather_ms"][:n])
+            assert all(st["device_kernel_ms"][i] > 0 for i in range(n) if b1[i] > b0[i])
+        # a new camera: a new plan, still the single-device frame
+        objs2, cam2 = capi.make_scene(kind, w, h, frame=40) if scene != "default" else (objs, capi.camera_init((1, 5, 9), (-.1, -.7, -1), 50.0, w, h))
+        multi.set_camera(cam2)
+        gpu_ctx.set_camera(cam2)
+        multi.render(p)
+        gpu_ctx.render(p)
+        assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), gpu_ctx.download(capi.RT_FMT_F32X4, w, h).view(np.uint32))
+        # a row range, the BMP body, and what a context over several devices does not do
+        rows = (h // 3, h - 1) if h > 8 else (1, 2)
+        multi.render(capi.render_params(w, h, depth, spp, rows=rows))
+        gpu_ctx.render(capi.render_params(w, h, depth, spp, rows=rows))
+        assert np.array_equal(multi.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]), gpu_ctx.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]))
+        with pytest.raises(capi.RtError) as e:
+            multi.render(capi.render_params(w, h, depth, spp, interleave=(2, 0)))
+        assert e.value.code == capi.RT_ERR_INVALID_ARG
+        with pytest.raises(capi.RtError) as e:
+            multi.render_noalloc(p, 16, 16, 16, 16)
+        assert e.value.code == capi.RT_ERR_INVALID_ARG
+    finally:
+        multi.close()
+
+
+def test_multi_device_errors(capi):
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 99)
+    assert capi.lib.rt_create_multi(C.byref(h), ids, 2) == capi.RT_ERR_INVALID_ARG and not h.value
+    assert capi.lib.rt_create_multi(C.byref(h), ids, 0) == capi.RT_ERR_INVALID_ARG
+    assert capi.lib.rt_create_multi(C.byref(h), None, 2) == capi.RT_ERR_INVALID_ARG
+    assert capi.lib.rt_create_multi(C.byref(h), (C.c_int * 9)(*([0] * 9)), 9) == capi.RT_ERR_INVALID_ARG

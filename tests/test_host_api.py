@@ -87,7 +87,8 @@ def test_host_program_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args,key", [(["-a", "0"], "a0"), ([], "a1"), (["-p", "8", "--antialiased=1"], "a1")])
+@pytest.mark.parametrize("args,key", [(["-a", "0"], "a0"), ([], "a1"), (["-p", "8", "--antialiased=1"], "a1"),
+                                      (["-g", "0,0,0"], "a1")])       # the frame shared three ways (rt_create_multi)
 def test_host_program_writes_reference_image(tmp_path, args, key):
     """raytracer_cpp's CLI contract: defaults -p 2 -a 1, image.bmp in the working directory, whose
     md5 is the one the verbatim program produced."""
