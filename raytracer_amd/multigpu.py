@@ -38,10 +38,12 @@ def prepass_row_cost(ctx, objs, cam, width, height, max_depth, factor=4):
 
     Leaves the full-size camera uploaded again on return."""
     lw, lh = max(1, -(-width // factor)), max(1, -(-height // factor))
-    ctx.upload_scene(objs, scaled_camera(cam, lw, lh))
-    ctx.render(capi.render_params(lw, lh, max_depth, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True))
-    f32 = ctx.download(capi.RT_FMT_F32X4, lw, lh)
-    ctx.upload_scene(objs, cam)
+    ctx.set_camera(scaled_camera(cam, lw, lh))       # the camera travels with each launch: nothing is uploaded
+    try:
+        ctx.render(capi.render_params(lw, lh, max_depth, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True))
+        f32 = ctx.download(capi.RT_FMT_F32X4, lw, lh)
+    finally:
+        ctx.set_camera(cam)
     return row_cost_from_prepass(f32[..., 3], height)
 
 
@@ -99,30 +101,31 @@ def gather_strips(part, width, rank, world, out=None, group=None, index_cache=No
 
 
 def gather_bands(band, bounds, rank, world, out=None, group=None):
-    """Gathers the bands to rank 0.
+    """Gathers the bands to rank 0, each straight into its rows of the frame.
 
-    band: torch tensor [max_rows, ...] whose first (bounds[rank+1]-bounds[rank]) rows are this rank's
-    rows; all ranks pass the same max_rows (padded gather, since RCCL's gather wants equal counts).
-    Returns the assembled [height, ...] tensor on rank 0 (written into `out` when given), else None."""
+    band: torch tensor [>= rows, ...] whose first bounds[rank+1]-bounds[rank] rows are this rank's.  Every
+    rank sends exactly its rows (RCCL send/recv: each peer has its own xGMI link to rank 0), and rank 0
+    receives them in place in `out[y0:y1]` -- no padding, no staging list, no allocation when `out` is given.
+    Returns the assembled [height, ...] tensor on rank 0 (`out` when given), else None."""
     import torch
     import torch.distributed as dist
 
     height = bounds[-1]
+    y0, y1 = bounds[rank], bounds[rank + 1]
     if world == 1:
-        rows = bounds[1] - bounds[0]
         if out is None:
-            return band[:rows]
-        out[:rows].copy_(band[:rows])
+            return band[: y1 - y0]
+        out[: y1 - y0].copy_(band[: y1 - y0])
         return out
-    parts = None
-    if rank == 0:
-        parts = [torch.empty_like(band) for _ in range(world)]
-    dist.gather(band, parts, dst=0, group=group)
     if rank != 0:
+        if y1 > y0:
+            dist.send(band[: y1 - y0], dst=0, group=group)
         return None
     if out is None:
         out = torch.empty((height,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
-    for r in range(world):
-        y0, y1 = bounds[r], bounds[r + 1]
-        out[y0:y1].copy_(parts[r][: y1 - y0])
+    ops = [dist.P2POp(dist.irecv, out[bounds[r]:bounds[r + 1]], r, group) for r in range(1, world) if bounds[r + 1] > bounds[r]]
+    out[y0:y1].copy_(band[: y1 - y0])
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return out

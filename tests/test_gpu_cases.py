@@ -616,3 +616,24 @@ def test_multi_device_errors(capi):
     assert capi.lib.rt_create_multi(C.byref(h), ids, 0) == capi.RT_ERR_INVALID_ARG
     assert capi.lib.rt_create_multi(C.byref(h), None, 2) == capi.RT_ERR_INVALID_ARG
     assert capi.lib.rt_create_multi(C.byref(h), (C.c_int * 9)(*([0] * 9)), 9) == capi.RT_ERR_INVALID_ARG
+
+
+def test_bands_rendered_by_the_hip_path_under_two_ranks(tmp_path):
+    """The N > 1 path of bench.py with every rank rendering its band through the HIP kernel: two processes
+    share GPU 0 (gloo carries the bands; on a multi-GPU node the same code runs over RCCL), and the frame
+    rank 0 assembles has the checksum of the N = 1 frame."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--width", "640", "--height", "362", "--spp", "4"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=170, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    crc1 = json.loads(one.stdout.strip().splitlines()[-1])["config"]["frame_crc"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common,
+                         capture_output=True, text=True, timeout=170, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["config"]["bands"]) == 3
+    assert line["config"]["frame_crc"] == crc1
