@@ -50,6 +50,7 @@ struct rt_context {
     void *pack_buf = nullptr;         // staging for the 24-bit download formats
     size_t pack_bytes = 0;
     RtStatsDev *stats_dev = nullptr;
+    unsigned long long *region_dev = nullptr;   // RT_AMD_REGION_DUMP=1 (profiling builds): the last launch's cycles by region
     void *scratch_dev = nullptr;      // this device's copy of `scratch` (rt_render_noalloc)
     const RtStatsDev *stats_src = nullptr;   // where the last render's counters are: stats_dev or scratch_dev
     rt_stats stats = {};
@@ -239,6 +240,7 @@ int rt_create(rt_context **out, int device_id)
     ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->stats_dev, sizeof(RtStatsDev));
     if (e == hipSuccess) e = scratch_for_device(device_id, &ctx->scratch_dev);     // device_id is current here
+    if (e == hipSuccess && getenv("RT_AMD_REGION_DUMP")) e = hipMalloc((void **)&ctx->region_dev, RT_N_REGIONS * sizeof(unsigned long long));
     if (e != hipSuccess) {
         fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e));
         rt_destroy(ctx);
@@ -308,6 +310,7 @@ void rt_destroy(rt_context *ctx)
     for (int i = 0; i < 2; i++)
         if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
     if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+    if (ctx->region_dev) (void)hipFree(ctx->region_dev);
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -695,7 +698,19 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     size_t off_gids = align(off_gpairs + grp.pairs.size() * sizeof(float4));
     size_t off_heads = align(off_gids + grp.ids.size() * sizeof(int32_t));
     size_t off_supers = align(off_heads + grp.heads.size() * sizeof(float4));
-    size_t total = align(off_supers + grp.supers.size() * sizeof(float4)) + 256;
+    // the same bounds one per float4 {g, R} (beam test: one bound per lane)
+    std::vector<float4> heads_flat((size_t)grp.n_groups), supers_flat((size_t)grp.n_supers);
+    auto unpair = [](const std::vector<float4> &rec, std::vector<float4> &dst) {
+        for (size_t g = 0; g < dst.size(); g++) {
+            const float4 A = rec[2 * (g >> 1)], B = rec[2 * (g >> 1) + 1];
+            dst[g] = (g & 1) ? make_float4(A.y, A.w, B.y, B.w) : make_float4(A.x, A.z, B.x, B.z);
+        }
+    };
+    unpair(grp.heads, heads_flat);
+    unpair(grp.supers, supers_flat);
+    size_t off_heads_flat = align(off_supers + grp.supers.size() * sizeof(float4));
+    size_t off_supers_flat = align(off_heads_flat + heads_flat.size() * sizeof(float4));
+    size_t total = align(off_supers_flat + supers_flat.size() * sizeof(float4)) + 256;
 
     std::vector<uint8_t> blob(total, 0);
     if (!pairs.empty()) memcpy(blob.data() + off_pairs, pairs.data(), pairs.size() * sizeof(float4));
@@ -708,6 +723,8 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (!grp.ids.empty()) memcpy(blob.data() + off_gids, grp.ids.data(), grp.ids.size() * sizeof(int32_t));
     if (!grp.heads.empty()) memcpy(blob.data() + off_heads, grp.heads.data(), grp.heads.size() * sizeof(float4));
     if (!grp.supers.empty()) memcpy(blob.data() + off_supers, grp.supers.data(), grp.supers.size() * sizeof(float4));
+    if (!heads_flat.empty()) memcpy(blob.data() + off_heads_flat, heads_flat.data(), heads_flat.size() * sizeof(float4));
+    if (!supers_flat.empty()) memcpy(blob.data() + off_supers_flat, supers_flat.data(), supers_flat.size() * sizeof(float4));
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // a render may still read the old scene
@@ -736,6 +753,9 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.heads = ctx->scene.supers = nullptr;
     ctx->scene.n_groups = ctx->scene.n_supers = 0;
     ctx->scene.metric[0] = ctx->scene.metric[1] = ctx->scene.metric[2] = ctx->scene.slack_scale = 1.0f;
+    ctx->scene.sigma[0] = ctx->scene.sigma[1] = ctx->scene.sigma[2] = 1.0f;
+    ctx->scene.heads_flat = ctx->scene.supers_flat = nullptr;
+    ctx->scene.beam_max_rho = ctx->scene.beam_max_chord2 = -1.0f;
     ctx->scene_grouped = ctx->scene;
     ctx->scene_grouped.pairs = (const float4 *)(base + off_gpairs);
     ctx->scene_grouped.sph_id = (const int32_t *)(base + off_gids);
@@ -744,6 +764,13 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene_grouped.supers = (const float4 *)(base + off_supers);
     ctx->scene_grouped.n_groups = grp.n_groups;
     ctx->scene_grouped.n_supers = grp.n_supers;
+    ctx->scene_grouped.heads_flat = (const float4 *)(base + off_heads_flat);
+    ctx->scene_grouped.supers_flat = (const float4 *)(base + off_supers_flat);
+    ctx->scene_grouped.beam_max_rho = 2.0f;
+    ctx->scene_grouped.beam_max_chord2 = 0.0625f;
+    if (const char *v = getenv("RT_AMD_BEAM_RHO")) ctx->scene_grouped.beam_max_rho = (float)atof(v);        // tuning knobs (A/B);
+    if (const char *v = getenv("RT_AMD_BEAM_CHORD2")) ctx->scene_grouped.beam_max_chord2 = (float)atof(v);  // a negative value turns the beam test off
+    for (int a = 0; a < 3; a++) ctx->scene_grouped.sigma[a] = grp.sigma[a];
     for (int a = 0; a < 3; a++) ctx->scene_grouped.metric[a] = grp.sigma[a] * grp.sigma[a];
     ctx->scene_grouped.slack_scale = grp.kappa * grp.kappa;
     ctx->cam = *cam;
@@ -1111,6 +1138,10 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     memcpy(smp.xy, p->sample_offsets ? p->sample_offsets : kRefPattern, sizeof(float) * 2 * (size_t)p->spp);
     if (p->lens_offsets) memcpy(smp.lens, p->lens_offsets, sizeof(float) * 2 * (size_t)p->spp);
 
+    if (ctx->region_dev && !na) {
+        fr.region_cycles = ctx->region_dev;
+        RT_HIP(ctx, hipMemsetAsync(ctx->region_dev, 0, RT_N_REGIONS * sizeof(unsigned long long), ctx->stream));
+    }
     RtStatsDev *sdev = nullptr;
     if (p->collect_stats) {
         // (the scratch array keeps the last call's counters: they start from zero every time)
@@ -1339,6 +1370,13 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     { int rc = drain_events(ctx, true); if (rc) return rc; }
+    if (ctx->region_dev) {                            // profiling builds (-DRT_REGION_TIMERS): wave-cycles by kernel region
+        unsigned long long h[RT_N_REGIONS];
+        RT_HIP(ctx, hipMemcpy(h, ctx->region_dev, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "rt region cycles:");
+        for (int i = 0; i < RT_N_REGIONS; i++) fprintf(stderr, " %llu", h[i]);
+        fprintf(stderr, "\n");
+    }
     ctx->stats.kernel_ms = ctx->kernel_ms_last;
     ctx->stats.kernel_ms_total = ctx->kernel_ms_total;
     ctx->stats.kernels_timed = ctx->kernels_timed;
@@ -1356,6 +1394,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
         ctx->stats.group_tests_run = h.group_tests_run;
         ctx->stats.exact_tests_run = h.exact_tests_run;
         ctx->stats_pending = false;
+
     }
     *out = ctx->stats;
     return RT_OK;

@@ -39,6 +39,7 @@
 #define RT_MAX_EMITTERS 64
 #define RT_GROUP_PAIRS 4      // pair records per group (8 spheres)
 #define RT_SUPER_GROUPS 8      // groups per super-group (64 spheres)
+#define RT_N_REGIONS 16
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
@@ -73,6 +74,12 @@ struct RtSceneDev {
     // the bounds are balls of the norm |x|_S = |diag(sigma) x| (ellipsoids, one shape per scene; sigma >= 1):
     float metric[3];      // sigma_a^2
     float slack_scale;    // max sigma^2: what a world-space allowance grows by in that norm
+    float sigma[3];
+    // the same bounds one per float4 {g, R}: the beam test puts one bound in each lane
+    const float4 *heads_flat;
+    const float4 *supers_flat;
+    float beam_max_rho, beam_max_chord2;   // a wave's rays go through the beam test while their origins lie within this
+                          // radius (in the bounds' norm) and each class's directions within this chord^2 of one another
 };
 
 struct RtFrameDev {
@@ -98,6 +105,9 @@ struct RtFrameDev {
                           // width of the output planes, whose column k is image column ((k / 8) * stride + phase) * 8 + k % 8
     int32_t first_tile_row;   // rt_render_params.first_row in tile rows of this band: launch order only
     int32_t cost_w;       // stats kernels: f32x4.w = work estimate instead of the ray count (RT_OUT_COST)
+    // profiling builds only (-DRT_REGION_TIMERS, tools/region_profile.sh; RT_AMD_REGION_DUMP=1 makes the library pass
+    // a buffer): RT_N_REGIONS sums of wave-cycles (s_memtime) by region of the trace kernel; NULL otherwise
+    unsigned long long *region_cycles;
 };
 
 struct RtStatsDev {
