@@ -371,9 +371,9 @@ def main():
             # committed rocprofv3 summary of this same command, and only while the kernel is the one profiled
             # (same private-segment size as the build that ships: raytracer_amd/kernel_resources.json)
             prof = os.path.join(ROOT, "profiles", "r2", "current_headline.csv")
-            tag = "trace_sweep_kernel<false, false, false, 6, false, true>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, false>"
+            tag = "trace_sweep_kernel<false, false, false, 6, false, 1>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, 0>"
             traffic, prof_scratch = profiled_traffic(prof, tag)
-            built = built_scratch_bytes("rt_sweep_grouped" if grouped else "rt_sweep_compact", "ILb0ELb0ELb0ELi6ELb0ELb1E" if grouped else "ILb0ELb1ELb0ELi6ELb0ELb0E")
+            built = built_scratch_bytes("rt_sweep_grouped" if grouped else "rt_sweep_compact", "ILb0ELb0ELb0ELi6ELb0ELi1E" if grouped else "ILb0ELb1ELb0ELi6ELb0ELi0E")
             same = traffic is not None and built is not None and prof_scratch == built
             out["roofline"]["traffic"] = traffic if same else None
             out["roofline"]["traffic_source"] = (os.path.relpath(prof, ROOT) + ": FETCH_SIZE + WRITE_SIZE per launch (bytes at the L2's memory "

@@ -78,6 +78,8 @@ struct RtSceneDev {
     // the same bounds one per float4 {g, R}: the beam test puts one bound in each lane
     const float4 *heads_flat;
     const float4 *supers_flat;
+    const float4 *supers2;    // paired records like `supers`, one level up: RT_SUPER_GROUPS consecutive super-groups each
+    int32_t n_supers2;
     float beam_max_rho, beam_max_chord2;   // a wave's rays go through the beam test while their origins lie within this
                           // radius (in the bounds' norm) and each class's directions within this chord^2 of one another
 };

@@ -29,6 +29,8 @@ hipError_t rt_launch_resolve_samples(const RtFrameDev &frame, hipStream_t stream
 
 hipError_t rt_launch_sweep_grouped(const RtSceneDev &, const rt_camera &, const RtFrameDev &, const RtSamples &, RtStatsDev *, bool,
                                    dim3, dim3, size_t, hipStream_t);
+hipError_t rt_launch_sweep_grouped3(const RtSceneDev &, const rt_camera &, const RtFrameDev &, const RtSamples &, RtStatsDev *, bool,
+                                    dim3, dim3, size_t, hipStream_t);
 hipError_t rt_launch_sweep_chunked(const RtSceneDev &, const rt_camera &, const RtFrameDev &, const RtSamples &, RtStatsDev *, bool,
                                    dim3, dim3, size_t, hipStream_t);
 hipError_t rt_launch_sweep_compact(const RtSceneDev &, const rt_camera &, const RtFrameDev &, const RtSamples &, RtStatsDev *, bool,
@@ -58,7 +60,8 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const size_t lds_bytes = grouped ? 256 : (size_t)(2 * cap + second) * sizeof(float4);   // grouped: the beams of the wave's ray classes
     const dim3 grid(one_wave ? units : (units + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
     if (chunked) return rt_launch_sweep_chunked(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
+    if (grouped && scene.n_supers > 64) return rt_launch_sweep_grouped3(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
     if (grouped) return rt_launch_sweep_grouped(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
     if (compact) return rt_launch_sweep_compact(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
-    return launch_sweep_class<false, false, false>(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
+    return launch_sweep_class<false, false, 0>(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
 }
