@@ -42,8 +42,8 @@ FLOP_PER_PLANE_TEST = 5
 
 
 def profiled_traffic(path, kernel):
-    """(bytes per launch, scratch bytes of the profiled kernel) from a committed rocprofv3 PMC summary of
-    this same command (tools/pmc_profile.sh): FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's
+    """(bytes per launch, scratch bytes of the profiled kernel, VALU busy fraction) from a committed rocprofv3 PMC summary of
+    this same command (tools/pmc_profile.sh), plus the VALU pipes' busy fraction: FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's
     gfx950 correction doubles FETCH_SIZE for wide streaming reads -- here most of the traffic is 4-byte
     private-memory (spill/record) accesses, a width the guide calls uncalibrated, so the uncorrected
     sum is reported and the note says so.  (None, None) when the summary is not there."""
@@ -59,9 +59,13 @@ def profiled_traffic(path, kernel):
             elif on and "," in line:
                 k, v = line.split(",")[:2]
                 rows[k] = v
-        return (float(rows["FETCH_SIZE"]) + float(rows["WRITE_SIZE"])) * 1024.0, scratch
+        busy = None
+        if "SQ_ACTIVE_INST_VALU" in rows and "GRBM_GUI_ACTIVE" in rows:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+            busy = 4.0 * float(rows["SQ_ACTIVE_INST_VALU"]) / 1024.0 / (float(rows["GRBM_GUI_ACTIVE"]) / 8.0)
+        return (float(rows["FETCH_SIZE"]) + float(rows["WRITE_SIZE"])) * 1024.0, scratch, busy
     except (OSError, KeyError, ValueError, IndexError):
-        return None, None
+        return None, None, None
 
 
 def built_scratch_bytes(unit, mangled_args):
@@ -372,10 +376,13 @@ def main():
             # (same private-segment size as the build that ships: raytracer_amd/kernel_resources.json)
             prof = os.path.join(ROOT, "profiles", "r2", "current_headline.csv")
             tag = "trace_sweep_kernel<false, false, false, 6, false, 1>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, 0>"
-            traffic, prof_scratch = profiled_traffic(prof, tag)
+            traffic, prof_scratch, valu_busy = profiled_traffic(prof, tag)
             built = built_scratch_bytes("rt_sweep_grouped" if grouped else "rt_sweep_compact", "ILb0ELb0ELb0ELi6ELb0ELi1E" if grouped else "ILb0ELb1ELb0ELi6ELb0ELi0E")
             same = traffic is not None and built is not None and prof_scratch == built
             out["roofline"]["traffic"] = traffic if same else None
+            # what the VALU pipes did, as opposed to what the tests were worth: the fraction of cycles a SIMD's VALU was
+            # issuing, from the same profile (the algorithmic `frac` falls as the sweep skips more tests; this does not)
+            out["roofline"]["valu_busy_profiled"] = valu_busy if same else None
             out["roofline"]["traffic_source"] = (os.path.relpath(prof, ROOT) + ": FETCH_SIZE + WRITE_SIZE per launch (bytes at the L2's memory "
                                                  "side, uncorrected: mostly 4-byte private-memory accesses, a width the guide calls uncalibrated); "
                                                  "profiled kernel scratch %s B, built kernel %s B%s" % (prof_scratch, built, "" if same else
