@@ -57,7 +57,7 @@ hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, 
     const bool one_wave = grouped || (!compact && !chunked);
     // LDS: flat = pairs | camera table, which the request queue aliases when compacting; grouped = none
     const int second = compact || chunked ? (2 * cap > kQueueFloat4 ? 2 * cap : kQueueFloat4) : 2 * cap;
-    const size_t lds_bytes = grouped ? 256 : (size_t)(2 * cap + second) * sizeof(float4);   // grouped: the beams of the wave's ray classes
+    const size_t lds_bytes = grouped ? kGroupedLdsBytes : (size_t)(2 * cap + second) * sizeof(float4);   // grouped: beams + ray state columns
     const dim3 grid(one_wave ? units : (units + kWavesPerBlock - 1) / kWavesPerBlock), block(one_wave ? 64 : kBlock);
     if (chunked) return rt_launch_sweep_chunked(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
     if (grouped && scene.n_supers > 64) return rt_launch_sweep_grouped3(scene, cam, frame, samples, stats, fast, grid, block, lds_bytes, stream);
