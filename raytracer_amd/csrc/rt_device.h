@@ -82,6 +82,9 @@ struct RtSceneDev {
     int32_t n_supers2;
     float beam_max_rho, beam_max_chord2;   // a wave's rays go through the beam test while their origins lie within this
                           // radius (in the bounds' norm) and each class's directions within this chord^2 of one another
+    float far_bound;      // a lane whose filter allowance (2^-19 |pos|^2) reaches this is so far from the origin that the
+                          // filter keeps spheres a good part of the scene's radius off its rays: its rays are tested
+                          // against every sphere, one ray at a time across the wave (dense_sweep); +inf: never
 };
 
 struct RtFrameDev {
