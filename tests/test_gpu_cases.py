@@ -360,6 +360,22 @@ def test_grouped_sweep_is_bit_identical(capi, gpu_ctx, scene, size, depth, spp):
         assert _same_frame(flat, grouped), (scene, size, mode)
 
 
+@pytest.mark.parametrize("fraction", ["1e-9", "0.02", "0"])
+def test_far_lanes_dense_sweep_is_bit_identical(capi, gpu_ctx, fraction, monkeypatch):
+    """The grouped sweep hands lanes far from the origin to dense_sweep (every sphere, one ray at a time across
+    the wave).  RT_AMD_FAR_FRACTION, read when a scene is uploaded, moves the threshold: 1e-9 sends every lane
+    that way, 0.02 a mix of lanes within most waves, 0 none; each must give the flat sweep's bits."""
+    for scene, (w, h), depth, spp in (("grid1k", (480, 270), 5, 4), ("grid16k", (320, 180), 3, 1)):
+        kind = {"grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[scene]
+        objs, cam = capi.make_scene(kind, w, h)
+        monkeypatch.delenv("RT_AMD_FAR_FRACTION", raising=False)
+        flat = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, sweep=capi.RT_SWEEP_FLAT)
+        monkeypatch.setenv("RT_AMD_FAR_FRACTION", fraction)
+        grouped = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, sweep=capi.RT_SWEEP_GROUPED)
+        monkeypatch.delenv("RT_AMD_FAR_FRACTION", raising=False)
+        assert _same_frame(flat, grouped), (scene, fraction)
+
+
 def test_grouped_sweep_random_cloud(capi, gpu_ctx):
     """5 000 spheres scattered in a volume (overlapping, some huge, lights inside the cloud): flat and
     grouped sweeps give the same bits at depth 8."""
