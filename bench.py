@@ -370,14 +370,20 @@ def main():
                                  "flat sweep that equals SURVEY 8d's 15 x rays x spheres; brute_force_equivalent = that "
                                  "count over this kernel's time; HBM traffic is the framebuffer only (4 B/px)"},
         }
-        if world == 1 and (args.scene, W, H, args.depth, args.spp, args.mode) == ("grid1k", 3840, 2160, 5, 4, "exact"):
+        # committed rocprofv3 summaries by workload: (file, kernel name in the trace, translation unit, mangled template arguments)
+        profiled = {
+            ("grid1k", 3840, 2160, 5, 4, "exact", True): ("current_headline.csv", "trace_sweep_kernel<false, false, false, 6, false, 1>", "rt_sweep_grouped", "ILb0ELb0ELb0ELi6ELb0ELi1E"),
+            ("grid1k", 3840, 2160, 5, 4, "exact", False): ("current_headline.csv", "trace_sweep_kernel<false, true, false, 6, false, 0>", "rt_sweep_compact", "ILb0ELb1ELb0ELi6ELb0ELi0E"),
+            ("grid16k", 3840, 2160, 5, 1, "exact", True): ("current_grid16k.csv", "trace_sweep_kernel<false, false, false, 6, false, 2>", "rt_sweep_grouped3", "ILb0ELb0ELb0ELi6ELb0ELi2E"),
+        }.get((args.scene, W, H, args.depth, args.spp, args.mode, bool(grouped)))
+        if world == 1 and profiled:
             # not measurable from inside this process (PMC counters need rocprofv3 around it): taken from the
             # committed rocprofv3 summary of this same command, and only while the kernel is the one profiled
             # (same private-segment size as the build that ships: raytracer_amd/kernel_resources.json)
-            prof = os.path.join(ROOT, "profiles", "r2", "current_headline.csv")
-            tag = "trace_sweep_kernel<false, false, false, 6, false, 1>" if grouped else "trace_sweep_kernel<false, true, false, 6, false, 0>"
+            prof = os.path.join(ROOT, "profiles", "r2", profiled[0])
+            tag = profiled[1]
             traffic, prof_scratch, valu_busy = profiled_traffic(prof, tag)
-            built = built_scratch_bytes("rt_sweep_grouped" if grouped else "rt_sweep_compact", "ILb0ELb0ELb0ELi6ELb0ELi1E" if grouped else "ILb0ELb1ELb0ELi6ELb0ELi0E")
+            built = built_scratch_bytes(profiled[2], profiled[3])
             same = traffic is not None and built is not None and prof_scratch == built
             out["roofline"]["traffic"] = traffic if same else None
             # what the VALU pipes did, as opposed to what the tests were worth: the fraction of cycles a SIMD's VALU was

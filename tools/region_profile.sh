@@ -9,7 +9,7 @@ RT_AMD_LIB=$LIB RT_AMD_REGION_DUMP=1 timeout -k 10 200 python bench.py --no-cpu 
 import sys
 names = ["ray generation", "primary: super-group bounds", "primary: group bounds", "primary: pair records (filter + exact tests)", "primary: planes, finish",
          "hit point, normal, material, reflect", "shadow-ray set-up", "segment: super-group bounds", "segment: group bounds",
-         "segment: pair records (filter + exact tests)", "planes + lit decisions", "records, next segment", "shading (backward pass)", "write-out", "segment sweeps of waves without beams (bounds + pairs)", "primary sweeps of waves without beams"]
+         "segment: pair records (filter + exact tests)", "planes + lit decisions", "records, next segment", "shading (backward pass)", "write-out", "sweeps without beams, only the reflection class wide (bounds + pairs)", "other sweeps without beams, far lanes (bounds + pairs)"]
 v = [int(x) for x in sys.stdin.read().split(":")[1].split()]
 t = sum(v)
 print("wave-cycles by region of the grouped kernel as timed (last launch) (s_memtime, summed over waves; %s)" % " ".join(sys.argv[1:]))
