@@ -360,6 +360,10 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": None,
+                         "achieved_kind": "algorithmic (reference-equivalent) FLOP/s: 15 FLOP per executed (ray, sphere) or (ray, bound) test as "
+                                          "SURVEY 8d prices the reference's test; the packed filter itself performs about 8 FLOP per (ray, sphere) "
+                                          "plus 10 shared by the K rays of a sphere pair, so this is not a VALU-issue fraction -- "
+                                          "valu_busy_profiled is",
                          "kernel_ms": k0_ms,
                          "algorithmic_flop_per_launch": int(my_flop),
                          "kernel": "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)",

@@ -789,7 +789,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (const char *v = getenv("RT_AMD_BEAM_CHORD2")) ctx->scene_grouped.beam_max_chord2 = (float)atof(v);  // a negative value turns the beam test off
     {
         // far lanes (rt_sweep_kernel.inc, dense_sweep): the filter keeps a sphere whose centre lies within about
-        // sqrt(r^2 + 1.25 * 2^-17 |pos|^2) of a ray's line; once that reaches half of the scene's radius the
+        // sqrt(r^2 + 1.25 * 2^-17 |pos|^2) of a ray's line; once that reaches half (large scenes: a quarter) of the scene's radius the
         // lane's rays are tested against everything instead.  (RT_AMD_FAR_FRACTION: A/B; <= 0 turns it off.)
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (size_t i = 0; i < geom.size(); i++) {
@@ -798,7 +798,10 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         }
         double diag2 = 0.0;
         for (int a = 0; a < 3; a++) diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
-        double fraction = 0.5;          // (measured, headline / 16k scene: 0.25 6.07 / 24.5 ms, 0.35 5.98 / 25.0, 0.5 5.90 / 25.0, 1 6.14 / 25.0, off 7.05 / 25.5)
+        // (measured, headline / 16k scene at 4K: 0.25 6.00 / 24.0 ms, 0.5 5.88 / 24.9, 1 6.14 / 25.0, off 7.05 / 25.5; the 16k scene at
+        // 1080p: 0.25 7.7 ms, 0.5 13.2 -- a wave that keeps a half-far lane walks most of the scene with all its lanes, which
+        // takes the longer the larger the scene is, and at lower resolutions that one wave is the frame)
+        double fraction = geom.size() <= 2048 ? 0.5 : 0.25;
         if (const char *v = getenv("RT_AMD_FAR_FRACTION")) fraction = atof(v);
         const double reach = fraction * 0.5 * std::sqrt(diag2);        // of the radius of the box around the spheres
         const double fb = reach * reach / 5.0;                          // allowance^2 = 5 * (2^-19 |pos|^2) = 5 * filter bound
@@ -1078,6 +1081,7 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)out_width * (size_t)(y1 - y0);
     ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
+    ctx->have_frame = false;          // until this render is queued: a failure below leaves no frame, not the previous one's description
     for (int i = 0; i < 2; i++) {
         if (!(outputs & (i ? RT_OUT_F32X4 : RT_OUT_RGBA8))) continue;
         const size_t need = px * (i ? 16 : 4);
@@ -1198,7 +1202,12 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
             if ((rc = drain_events(ctx, false))) return rc;
         }
     }
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the pair goes back to the pool on every early return below (a failed launch must not leak events)
+    struct EventPair {
+        rt_context *c; hipEvent_t *a, *b; bool keep = false;
+        ~EventPair() { if (!keep) { if (*a) c->ev_free.push_back(*a); if (*b) c->ev_free.push_back(*b); } }
+    } pair_guard{ctx, &ev0, &ev1};
     { int rc = take_event(ctx, &ev0); if (rc) return rc; rc = take_event(ctx, &ev1); if (rc) return rc; }
     RT_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     if (px > 0) {
@@ -1211,6 +1220,7 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     }
     RT_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     ctx->ev_pending.emplace_back(ev0, ev1);
+    pair_guard.keep = true;
     }
 
     ctx->stats_src = sdev;
