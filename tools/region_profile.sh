@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do the trace kernel's wave-cycles go?  Needs a profiling build of the grouped sweep:
-#   cd raytracer_amd/csrc && hipcc <flags of the Makefile> -DRT_REGION_TIMERS -c rt_sweep_grouped.hip -o build_rt/rt_sweep_grouped.o
+#   cd raytracer_amd/csrc && hipcc <flags of the Makefile> -DRT_REGION_TIMERS -c rt_sweep_grouped.hip -o build_rt/rt_sweep_grouped.o   (and rt_sweep_grouped3.hip likewise)
 #   and a library linked from it: raytracer_amd/librt_amd_regions.so
 # usage (GPU box): bash tools/region_profile.sh [bench.py options] > gpurun_out/regions.txt
 set -e
