@@ -175,9 +175,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="frames in flight per rank (each lane: its own context, stream and band buffer); 0 = 1 for one "
                          "GPU, 2 for N > 1 so that the gather of frame k runs under the render of frame k + 1")
-    ap.add_argument("--plan", default="bands", choices=["bands", "strips"],
-                    help="N > 1: contiguous cost-balanced row bands (default; measured the better of the two), or "
-                         "8-column strips dealt round-robin to the ranks")
+    ap.add_argument("--plan", default="auto", choices=["auto", "bands", "strips"],
+                    help="N > 1: 8-column strips dealt round-robin to the ranks (what auto picks when the width is a multiple "
+                         "of 8 x gpus: every rank gets the same share of every row, slowest of 8 parts 1.05x the mean), or "
+                         "contiguous cost-balanced row bands (1.12x; auto's fallback)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with all ranks sharing GPU 0 (bands staged through the host)")
@@ -217,7 +218,7 @@ def main():
     # the plan is identical on every rank without communication: contiguous row bands balanced by a
     # deterministic 1/16-resolution pre-pass, or strips of 8 columns dealt round-robin (every rank gets
     # the same share of every row; no pre-pass, but measured no better: DESIGN.md section 5)
-    strips = world > 1 and args.plan == "strips"
+    strips = world > 1 and (args.plan == "strips" or (args.plan == "auto" and args.width % (8 * world) == 0))
     out_w = W
     if strips:
         bounds = None
