@@ -634,10 +634,11 @@ def test_multi_device_errors(capi):
     assert capi.lib.rt_create_multi(C.byref(h), (C.c_int * 9)(*([0] * 9)), 9) == capi.RT_ERR_INVALID_ARG
 
 
-def test_bands_rendered_by_the_hip_path_under_two_ranks(tmp_path):
-    """The N > 1 path of bench.py with every rank rendering its band through the HIP kernel: two processes
-    share GPU 0 (gloo carries the bands; on a multi-GPU node the same code runs over RCCL), and the frame
-    rank 0 assembles has the checksum of the N = 1 frame."""
+@pytest.mark.parametrize("plan", ["bands", "strips"])
+def test_bands_rendered_by_the_hip_path_under_two_ranks(tmp_path, plan):
+    """The N > 1 path of bench.py with every rank rendering its part (a cost-balanced band, or its 8-column
+    strips) through the HIP kernel: two processes share GPU 0 (gloo carries the parts; on a multi-GPU node the
+    same code runs over RCCL), and the frame rank 0 assembles has the checksum of the N = 1 frame."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -647,9 +648,9 @@ def test_bands_rendered_by_the_hip_path_under_two_ranks(tmp_path):
     crc1 = json.loads(one.stdout.strip().splitlines()[-1])["config"]["frame_crc"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common,
+                          "--master-port", "29541" if plan == "bands" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plan", plan] + common,
                          capture_output=True, text=True, timeout=170, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     line = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and len(line["config"]["bands"]) == 3
+    assert line["n_gpus"] == 2 and (len(line["config"]["bands"]) == 3 if plan == "bands" else "strips" in line["config"]["parallelism"])
     assert line["config"]["frame_crc"] == crc1
