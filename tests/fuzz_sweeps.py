@@ -29,7 +29,7 @@ def random_scene(capi, rng):
     """Spheres in a slab, a blob, a shell or a line (clustered, overlapping, tiny and huge radii),
     0-3 planes, 1-6 emitters, list order shuffled."""
     M, S, P = capi.material, capi.sphere, capi.tiled_plane
-    n = int(rng.choice([3, 17, 64, 65, 200, 700, 2500]))
+    n = int(rng.choice([3, 17, 64, 65, 200, 700, 2500, 5500]))      # (5500: the large-scene instantiation of the grouped sweep, > 64 super-groups)
     layout = rng.choice(["slab", "blob", "shell", "line"])
     scale = float(rng.choice([1.0, 10.0, 300.0]))
     items = []
