@@ -278,6 +278,9 @@ def main():
         c.set_stream(s_.cuda_stream)
         lanes.append((c, s_, b, f))
     issued = [0]
+    if strips and rank == 0 and not rehearsal:
+        for _, _, b_, _ in lanes:                           # the gather's receive buffers exist before anything is timed
+            multigpu.strip_receive_buffer(strip_index, b_, world)
 
     def step():
         c, stream, b, f = lanes[issued[0] % n_lanes]
@@ -314,11 +317,13 @@ def main():
     fence()
     before = lane_stats()
     fence()
+    allocs0 = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    timed_allocs = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0) - allocs0
     after = lane_stats()
     assert after[0] - before[0] == args.steps
     kernel_ms = after[1] - before[1]
@@ -357,6 +362,7 @@ def main():
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                                                                          "sphere_tests", "sphere_tests_run", "group_tests_run", "exact_tests_run")},
                        "lanes": n_lanes,
+                       "device_allocations_in_timed_region_rank0": int(timed_allocs),
                        "parallelism": (f"8-column strips round-robin x{world}" if strips else f"row-bands x{world}") + ((" + gloo gather (rehearsal)" if rehearsal else " + RCCL gather") if world > 1 else "")},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,

@@ -334,6 +334,7 @@ struct GroupedScene {
     std::vector<float4> supers;    // 2 * ceil(n_supers / 2)
     std::vector<float4> supers2;   // 2 * ceil(n_supers2 / 2): bounds of RT_SUPER_GROUPS consecutive super-groups
     int n_groups = 0, n_supers = 0, n_supers2 = 0;
+    int n_tail_pairs = 0;                  // records after the groups' that every sweep tests (the emissive spheres, when few)
     float sigma[3] = {1.0f, 1.0f, 1.0f};   // the metric the bounds are measured in: |x|_S = |diag(sigma) x|, min sigma = 1
     float kappa = 1.0f;                    // max sigma
 };
@@ -395,8 +396,14 @@ static double reach_S(const double v[3], double r, const double sig[3])
     return std::min(crude, best * (1.0 + 1e-9));
 }
 
+// Emissive spheres are kept apart: every shadow ray is aimed at one of them, so whatever bounds them they are visited by
+// every sweep that carries shadow rays -- a light in a group of its own (what the radius cap gives a far-away light)
+// costs such a sweep a visit of four records per light, three of them padding.  Up to 8 emissive spheres become the
+// TAIL instead: pair records after the last group's, under no bound, that every sweep tests (n_tail_pairs; measured
+// on the 1028-sphere scene with its 4 lights: 5.77 -> 5.2 ms per frame).  More than 8 are grouped among themselves,
+// 8 to a group in the order of the curve, after all other groups, under bounds like any group.
 static void build_groups(const std::vector<float4> &geom, const std::vector<float> &radius,
-                         const std::vector<int32_t> &sph_id, GroupedScene &out)
+                         const std::vector<int32_t> &sph_id, const std::vector<char> &emissive, GroupedScene &out)
 {
     const size_t n = geom.size();
     const int kMax = 2 * RT_GROUP_PAIRS;
@@ -472,6 +479,7 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
         groups.push_back(g);
         cur.clear();
     };
+    const bool emitters_apart = !getenv("RT_AMD_NO_EMIT_GROUPS");       // (A/B knob)
     for (size_t k = 0; k < n; k++) {
         const uint32_t i = order[k].second;
         if (!finite[i]) {                   // never hit by anything (dSquared is NaN or r*r is inf): own group
@@ -480,6 +488,7 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
             close();
             continue;
         }
+        if (emitters_apart && emissive[i]) continue;      // below
         if ((int)cur.size() == kMax) close();
         if (!cur.empty()) {
             std::vector<uint32_t> trial = cur;
@@ -491,6 +500,21 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
         cur.push_back(i);
     }
     close();
+    std::vector<uint32_t> tail;                                  // at most kMax emissive spheres: no group, no bound
+    {
+        std::vector<uint32_t> em;
+        for (size_t k = 0; emitters_apart && k < n; k++)
+            if (finite[order[k].second] && emissive[order[k].second]) em.push_back(order[k].second);
+        if (em.size() <= (size_t)kMax && !getenv("RT_AMD_NO_TAIL")) {
+            tail = em;
+        } else {
+            for (uint32_t i : em) {                              // along the same curve, 8 to a group
+                if ((int)cur.size() == kMax) close();
+                cur.push_back(i);
+            }
+            close();
+        }
+    }
 
     // The metric of the bounds.  Spheres standing on a floor make groups that are wide and flat; a round
     // bound of such a group is mostly air above it, and every ray that rises through that air visits the
@@ -547,11 +571,14 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
 
     out.n_groups = (int)groups.size();
     const float kNoHit = 3.402823466e+38f;
-    out.pairs.assign((size_t)2 * RT_GROUP_PAIRS * groups.size(), make_float4(0.0f, 0.0f, kNoHit, kNoHit));
-    out.ids.assign((size_t)kMax * groups.size(), -1);
-    for (size_t g = 0; g < groups.size(); g++) {
-        for (int p = 0; p < RT_GROUP_PAIRS; p++) out.pairs[2 * (g * RT_GROUP_PAIRS + p)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        std::vector<uint32_t> &m = groups[g].members;
+    out.n_tail_pairs = (int)((tail.size() + 1) / 2);
+    const size_t n_records = (size_t)RT_GROUP_PAIRS * groups.size() + (size_t)out.n_tail_pairs;
+    out.pairs.assign(2 * n_records, make_float4(0.0f, 0.0f, kNoHit, kNoHit));
+    out.ids.assign(2 * n_records, -1);
+    for (size_t p = 0; p < n_records; p++) out.pairs[2 * p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (size_t g = 0; g <= groups.size(); g++) {       // (the last round: the tail, laid out like one more group)
+        if (g == groups.size() && tail.empty()) break;
+        std::vector<uint32_t> &m = g < groups.size() ? groups[g].members : tail;
         std::sort(m.begin(), m.end());      // list order inside a group: most ties resolve by slot order already
         for (size_t j = 0; j < m.size(); j++) {
             const size_t slot = g * kMax + j, pr = slot >> 1;
@@ -696,7 +723,10 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     }
 
     GroupedScene grp;
-    build_groups(geom, radius, sph_id, grp);
+    std::vector<char> emissive(geom.size(), 0);
+    for (const RtEmitterDev &e : emit)
+        if (!e.is_plane) emissive[(size_t)e.sphere_slot] = 1;
+    build_groups(geom, radius, sph_id, emissive, grp);
 
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off_pairs = 0;
@@ -764,7 +794,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_emit = (int32_t)emit.size();
     ctx->scene.n_pairs = (int32_t)(pairs.size() / 2);
     ctx->scene.heads = ctx->scene.supers = nullptr;
-    ctx->scene.n_groups = ctx->scene.n_supers = 0;
+    ctx->scene.n_groups = ctx->scene.n_supers = ctx->scene.n_tail_pairs = 0;
     ctx->scene.metric[0] = ctx->scene.metric[1] = ctx->scene.metric[2] = ctx->scene.slack_scale = 1.0f;
     ctx->scene.sigma[0] = ctx->scene.sigma[1] = ctx->scene.sigma[2] = 1.0f;
     ctx->scene.heads_flat = ctx->scene.supers_flat = ctx->scene.supers2 = nullptr;
@@ -778,6 +808,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene_grouped.n_pairs = (int32_t)(grp.pairs.size() / 2);
     ctx->scene_grouped.supers = (const float4 *)(base + off_supers);
     ctx->scene_grouped.n_groups = grp.n_groups;
+    ctx->scene_grouped.n_tail_pairs = grp.n_tail_pairs;
     ctx->scene_grouped.n_supers = grp.n_supers;
     ctx->scene_grouped.supers2 = (const float4 *)(base + off_supers2);
     ctx->scene_grouped.n_supers2 = grp.n_supers2;
@@ -822,15 +853,17 @@ int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t
     std::vector<float4> geom;
     std::vector<float> radius;
     std::vector<int32_t> sph_id;
+    std::vector<char> emissive;
     for (int32_t k = 0; k < n; k++) {
         if (group_of_object) group_of_object[k] = -1;
         if (objs[k].type != RT_OBJ_SPHERE) continue;
         geom.push_back(make_float4(objs[k].a[0], objs[k].a[1], objs[k].a[2], objs[k].radius * objs[k].radius));
         radius.push_back(objs[k].radius);
         sph_id.push_back(k);
+        emissive.push_back(emissive_nonzero(objs[k].mat) ? 1 : 0);
     }
     GroupedScene grp;
-    build_groups(geom, radius, sph_id, grp);
+    build_groups(geom, radius, sph_id, emissive, grp);
     *n_groups = grp.n_groups;
     *n_supers = grp.n_supers;
     for (int a = 0; sigma && a < 3; a++) sigma[a] = grp.sigma[a];
@@ -847,8 +880,10 @@ int rt_plan_groups(const rt_object *objs, int32_t n, int32_t max_groups, int32_t
     };
     unpack(grp.heads, grp.n_groups, group_bounds);
     unpack(grp.supers, grp.n_supers, super_bounds);
-    for (size_t i = 0; group_of_object && i < sph_id.size(); i++)
-        group_of_object[sph_id[i]] = grp.slot_of[i] / (2 * RT_GROUP_PAIRS);
+    for (size_t i = 0; group_of_object && i < sph_id.size(); i++) {
+        const int g = grp.slot_of[i] / (2 * RT_GROUP_PAIRS);
+        group_of_object[sph_id[i]] = g < grp.n_groups ? g : -1;        // (the tail -- emissive spheres under no bound -- has no group)
+    }
     return RT_OK;
 }
 

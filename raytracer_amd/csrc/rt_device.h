@@ -71,6 +71,8 @@ struct RtSceneDev {
     const float4 *heads;  // grouped layout only: bounding spheres of the groups ...
     const float4 *supers; // ... and of the super-groups (RT_SUPER_GROUPS consecutive groups each)
     int32_t n_groups, n_supers;
+    int32_t n_tail_pairs; // grouped layout: pair records after the last group's that EVERY sweep tests, bounds unasked -- the
+                          // emissive spheres of a scene with at most 8 of them (every shadow ray is aimed at one)
     // the bounds are balls of the norm |x|_S = |diag(sigma) x| (ellipsoids, one shape per scene; sigma >= 1):
     float metric[3];      // sigma_a^2
     float slack_scale;    // max sigma^2: what a world-space allowance grows by in that norm

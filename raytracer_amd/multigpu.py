@@ -68,6 +68,16 @@ def interleaved_col_index(width, world, rank):
     return cols[cols < width]
 
 
+def strip_receive_buffer(cache, part, world):
+    """Rank 0's receive buffer of gather_strips ([world, rows, max_cols, ...]), made on first use and kept in `cache`:
+    call it at set-up so that no frame of a timed loop allocates."""
+    import torch
+    key = ("recv", world, tuple(part.shape), part.dtype, str(part.device))
+    if key not in cache:
+        cache[key] = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
+    return cache[key]
+
+
 def gather_strips(part, width, rank, world, out=None, group=None, index_cache=None):
     """Gathers interleaved renders (render_params(interleave=(world, rank))) to rank 0 and puts every strip
     in its place.  part: torch tensor [rows, max_cols, ...] whose first interleaved_count(width, world, rank)
@@ -75,28 +85,54 @@ def gather_strips(part, width, rank, world, out=None, group=None, index_cache=No
     (a render's own planes are exactly its count wide: when the shares differ, i.e. width is not a multiple of
     8 x world, copy them into the padded tensor first; with equal shares the render can write into it directly).
     Returns the assembled [rows, width, ...] tensor on rank 0 (written into `out` when given), else None.
-    index_cache: a dict the caller keeps between frames (the column indices live on the tensor's device)."""
+
+    index_cache: a dict the caller keeps between frames.  It holds rank 0's receive buffer ([world, rows, max_cols,
+    ...], allocated on the first call and reused: with `out` and `index_cache` given, later calls allocate nothing
+    on the device) and, for unequal shares, the column indices.  With equal shares (width a multiple of 8 x world)
+    the strips go to their places in ONE strided copy: the frame seen as [rows, width / (8 world), world, 8] is
+    the receive buffer [world, rows, width / (8 world), 8] with its axes permuted."""
     import torch
     import torch.distributed as dist
 
-    parts = None
+    cache = index_cache if index_cache is not None else {}
+    s = capi.RT_STRIP_COLS
+    stack = None
     if world > 1:
+        parts = None
         if rank == 0:
-            parts = [torch.empty_like(part) for _ in range(world)]
+            stack = strip_receive_buffer(cache, part, world)
+            parts = list(stack.unbind(0))                 # views of the one buffer: no device allocation
         dist.gather(part, parts, dst=0, group=group)
         if rank != 0:
             return None
     else:
-        parts = [part]
-    if out is None:
-        out = torch.empty((part.shape[0], width) + tuple(part.shape[2:]), dtype=part.dtype, device=part.device)
+        stack = part.unsqueeze(0)
+    return assemble_strips(stack, width, out=out, index_cache=cache)
+
+
+def assemble_strips(stack, width, out=None, index_cache=None):
+    """stack[r] = rank r's strips side by side ([world, rows, max_cols, ...]) -> the frame [rows, width, ...].
+    Equal shares (width a multiple of 8 x world): one strided copy, no index tensors, nothing allocated when `out`
+    is given.  Otherwise one column scatter per rank (indices cached in `index_cache`)."""
+    import torch
+
     cache = index_cache if index_cache is not None else {}
+    s = capi.RT_STRIP_COLS
+    world, rows, cols = stack.shape[0], stack.shape[1], stack.shape[2]
+    tail = tuple(stack.shape[3:])
+    if out is None:
+        out = torch.empty((rows, width) + tail, dtype=stack.dtype, device=stack.device)
+    if width % (s * world) == 0 and cols * world == width and out.is_contiguous() and stack.is_contiguous():
+        t = len(tail)
+        src = stack.view((world, rows, cols // s, s) + tail).permute((1, 2, 0, 3) + tuple(range(4, 4 + t)))
+        out.view((rows, cols // s, world, s) + tail).copy_(src)
+        return out
     for r in range(world):
-        key = (width, world, r, str(part.device))
+        key = (width, world, r, str(stack.device))
         if key not in cache:
-            cache[key] = torch.from_numpy(interleaved_col_index(width, world, r).astype(np.int64)).to(part.device)
+            cache[key] = torch.from_numpy(interleaved_col_index(width, world, r).astype(np.int64)).to(stack.device)
         idx = cache[key]
-        out.index_copy_(1, idx, parts[r][:, : idx.numel()])
+        out.index_copy_(1, idx, stack[r][:, : idx.numel()])
     return out
 
 

@@ -12,7 +12,7 @@ oracle/ref_trace_harness.cpp and oracle/Makefile), and every whole-path pin belo
 image.bmp md5s, radiance, call counters, the synthetic scenes at depth 5 and 8, the edge scenes at
 depth 0/1/5/15, the 1080p and 4K-16spp frames of BASELINE's configs 2 and 3.
 
-Usage: make -C oracle && python tests/gen_golden.py
+Usage: make -C oracle && python tests/gen_golden.py        (`... gen_golden.py headline`: only headline_4spp.json)
 """
 import ctypes as C
 import hashlib
@@ -153,6 +153,34 @@ def gen_scene_pins(rng):
                          "full-resolution sparse-pixel pins", "scenes": scenes}, open(os.path.join(OUT, "scenes.json"), "w"))
 
 
+def gen_headline_pins():
+    """bench.py's own launch configuration (grid-1024, frame 0, 3840x2160, MAX_DEPTH 5, 4 spp: the samples-in-lanes
+    layout of the grouped sweep): 192 pixels x the four offsets of main.cpp:202 through the verbatim TraceRay, summed
+    in sample order and scaled by 1/4 as main.cpp:203-210 does (float adds in that order).  Own file, own RNG, so
+    that adding it moved no other fixture: `python tests/gen_golden.py headline` writes only this one."""
+    w, h, depth, spp, n_px = 3840, 2160, 5, 4, 192
+    rng = np.random.default_rng(0x4EAD11)
+    objs, cam = capi.make_scene(1, w, h)
+    r = ref_trace(depth)
+    r.set_scene(objs, cam)
+    # a third of the pixels from the rows under the horizon (the far-lane path), the rest anywhere
+    px = np.stack([rng.integers(0, w, n_px), rng.integers(0, h, n_px)], axis=1)
+    px[: n_px // 3, 1] = rng.integers(0, h // 4, n_px // 3)
+    sxy = (px[:, None, :].astype(np.float32) + REF_PATTERN.reshape(4, 2)[None, :spp, :]).astype(np.float32).reshape(-1, 2)
+    rad = r.trace_samples(sxy, threads=8).reshape(n_px, spp, 3).astype(np.float32)
+    color = np.zeros((n_px, 3), dtype=np.float32)
+    for s in range(spp):
+        color = (color + rad[:, s, :]).astype(np.float32)              # main.cpp:208
+    color = (color * np.float32(1.0 / spp)).astype(np.float32)          # main.cpp:210
+    json.dump({"source": "rt_make_scene(grid1k, frame 0) + the reference's own TraceRay (oracle/_ref/libref_trace_d5.so), "
+                         "4 samples per pixel summed and scaled as main.cpp:203-210",
+               "kind": 1, "w": w, "h": h, "depth": depth, "spp": spp, "frame": 0, "n": len(objs),
+               "objects_sha256": hashlib.sha256(bytes(objs)).hexdigest(), "camera": cam_bits(cam),
+               "pixels": px.reshape(-1).tolist(), "sample_radiance": bits(rad.reshape(-1)), "radiance": bits(color.reshape(-1))},
+              open(os.path.join(OUT, "headline_4spp.json"), "w"))
+    print("headline pins: %d pixels x %d samples" % (n_px, spp), flush=True)
+
+
 def gen_edge_pins():
     """Whole small frames of tests/edge_scenes.py through the reference's TraceRay at MAX_DEPTH 0/1/5/15,
     spp 1 and 4: sha256 of the radiance bits and of the 8-bit image, plus a few radiance values to look at."""
@@ -198,6 +226,10 @@ def gen_config_pins():
 
 
 def main():
+    if sys.argv[1:] == ["headline"]:
+        os.makedirs(OUT, exist_ok=True)
+        gen_headline_pins()
+        return
     ref = oracle_lib.load_ref()
     if ref is None:
         raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle` where /root/reference exists")
@@ -320,6 +352,7 @@ def main():
     gen_scene_pins(rng)
     gen_edge_pins()
     gen_config_pins()
+    gen_headline_pins()
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -96,8 +96,13 @@ def _strip_worker(rank, world, port, w, h, q):
         part[:, : len(cols)] = torch.from_numpy(np.ascontiguousarray(full[:, cols]))
         cache = {}
         frame = multigpu.gather_strips(part, w, rank, world, index_cache=cache)
-        again = multigpu.gather_strips(part, w, rank, world, index_cache=cache)       # cached indices
+        recv = {k: v.data_ptr() for k, v in cache.items() if k[0] == "recv"}
+        out = torch.zeros((h, w, 3), dtype=torch.uint8) if rank == 0 else None
+        again = multigpu.gather_strips(part, w, rank, world, out=out, index_cache=cache)   # cached receive buffer and indices
         if rank == 0:
+            # the second call reuses the first call's receive buffer and writes into `out`: nothing new is allocated
+            assert len(recv) == 1 and recv == {k: v.data_ptr() for k, v in cache.items() if k[0] == "recv"}
+            assert again is out
             q.put(("ok", bool(np.array_equal(frame.numpy(), full) and np.array_equal(again.numpy(), full)), None))
         else:
             assert frame is None and again is None
@@ -108,11 +113,11 @@ def _strip_worker(rank, world, port, w, h, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,w", [(2, 96), (3, 91)])
+@pytest.mark.parametrize("world,w", [(2, 96), (3, 91), (3, 120)])
 def test_strip_gather_gloo(world, w):
     """8-column strips dealt round-robin (rt_render_params.col_interleave): the padded gather and the
     column scatter on rank 0 rebuild the single-process frame, also when the last strip is narrow and
-    the shares are unequal."""
+    the shares are unequal (equal shares take the one-copy path, unequal ones the per-rank column scatter)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

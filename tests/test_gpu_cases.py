@@ -85,6 +85,14 @@ def test_full_size_sparse_pixels(capi, gpu_ctx, sweep):
         want = np.asarray(s["radiance"], dtype=np.uint32).reshape(-1, 3)
         got = f32[px[:, 1], px[:, 0], :3].view(np.uint32)
         assert np.array_equal(got, want), name
+    # bench.py's own launch configuration: the headline frame with 4 samples per pixel (the grouped sweep then puts the
+    # samples in lanes, 4x4 pixels per wave) against the reference's TraceRay summed as main.cpp:203-210 does
+    g = json.load(open(os.path.join(GOLD, "headline_4spp.json")))
+    objs, cam = capi.make_scene(g["kind"], g["w"], g["h"], frame=g["frame"])
+    assert hashlib.sha256(bytes(objs)).hexdigest() == g["objects_sha256"]
+    _, f32 = render_gpu(capi, gpu_ctx, objs, cam, g["w"], g["h"], g["depth"], g["spp"], sweep=sweep)
+    px = np.asarray(g["pixels"]).reshape(-1, 2)
+    assert np.array_equal(f32[px[:, 1], px[:, 0], :3].view(np.uint32), np.asarray(g["radiance"], dtype=np.uint32).reshape(-1, 3)), "headline 4 spp"
 
 
 @pytest.mark.parametrize("sweep", [1, 2])
@@ -145,6 +153,34 @@ def test_col_interleave_tiles_the_frame(capi, gpu_ctx, scene, size, spp, n):
             assert np.array_equal(outs[0], outs[1])
     with pytest.raises(capi.RtError):
         gpu_ctx.render(capi.render_params(w, h, 5, 1, first_row=h))
+
+
+def test_strip_assembly_is_one_copy_and_allocates_nothing(capi, gpu_ctx):
+    """multigpu.assemble_strips (rank 0's half of gather_strips) on the device: four interleaved renders written
+    straight into the four slices of one receive buffer, put in place by ONE strided copy; the result is the full
+    frame, and a second assembly into the same `out` makes no device allocation (torch's allocator counts)."""
+    import torch
+    from raytracer_amd import multigpu
+    w, h, n = 640, 360, 4
+    objs, cam = capi.make_scene(capi.RT_SCENE_GRID1K, w, h)
+    gpu_ctx.upload_scene(objs, cam)
+    rgb_full, _ = render_gpu(capi, gpu_ctx, objs, cam, w, h, 5, 4)
+    dev = torch.device("cuda", 0)
+    stack = torch.zeros((n, h, w // n), dtype=torch.int32, device=dev)
+    out = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    for phase in range(n):
+        gpu_ctx.bind_framebuffer(capi.RT_OUT_RGBA8, stack[phase].data_ptr(), stack[phase].numel() * 4)
+        gpu_ctx.render(capi.render_params(w, h, 5, 4, interleave=(n, phase)))
+    gpu_ctx.bind_framebuffer(capi.RT_OUT_RGBA8, 0, 0)
+    cache = {}
+    multigpu.assemble_strips(stack, w, out=out, index_cache=cache)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+    again = multigpu.assemble_strips(stack, w, out=out, index_cache=cache)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0) == before and not cache and again is out
+    got = out.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+    assert np.array_equal(got[..., :3], rgb_full) and np.all(got[..., 3] == 255)
 
 
 def test_prepass_band_plan(capi, gpu_ctx):
@@ -654,3 +690,6 @@ def test_bands_rendered_by_the_hip_path_under_two_ranks(tmp_path, plan):
     line = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and (len(line["config"]["bands"]) == 3 if plan == "bands" else "strips" in line["config"]["parallelism"])
     assert line["config"]["frame_crc"] == crc1
+    # nothing is allocated on the device between the two fences of the timed region (rank 0: renders, gather, assembly)
+    assert line["config"]["device_allocations_in_timed_region_rank0"] == 0
+    assert json.loads(one.stdout.strip().splitlines()[-1])["config"]["device_allocations_in_timed_region_rank0"] == 0

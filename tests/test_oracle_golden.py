@@ -323,6 +323,27 @@ def test_scene_generators_and_sparse_radiance(oracle, capi):
         assert same_bits(rad.reshape(-1), fl(s["radiance"])), name
 
 
+def test_headline_workload_4spp_pins(oracle, capi):
+    """bench.py's own workload (grid-1024 at 3840x2160, MAX_DEPTH 5, 4 spp): the oracle's per-sample radiance and the
+    pixel value after main.cpp:203-210's sum and scale, for 192 pixels, against the reference's own TraceRay
+    (tests/golden/headline_4spp.json); a third of the pixels lie in the rows under the horizon."""
+    g = load("headline_4spp.json")
+    objs, cam = capi.make_scene(g["kind"], g["w"], g["h"], frame=g["frame"])
+    assert len(objs) == g["n"] and hashlib.sha256(bytes(objs)).hexdigest() == g["objects_sha256"]
+    assert same_bits(_cam_list(cam), fl(g["camera"]))
+    px = np.asarray(g["pixels"]).reshape(-1, 2)
+    pattern = np.asarray([0.1, 0.2, 0.6, 0.5, 0.8, 0.7, 0.2, 0.8], dtype=np.float32).reshape(4, 2)
+    sxy = (px[:, None, :].astype(np.float32) + pattern[None, : g["spp"], :]).astype(np.float32).reshape(-1, 2)
+    rad = oracle.trace_samples(objs, cam, g["depth"], sxy)
+    assert same_bits(rad.reshape(-1), fl(g["sample_radiance"]))
+    # the oracle's own pixel loop on the rows that hold those pixels: same sum, same scale
+    for y in sorted(set(px[:8, 1].tolist())):
+        _, f32, _ = oracle.render(objs, cam, capi.render_params(g["w"], g["h"], g["depth"], g["spp"], rows=(y, y + 1)), threads=8, want_rgb8=False)
+        row = f32[y] if f32.shape[0] == g["h"] else f32[0]
+        for i in np.nonzero(px[:, 1] == y)[0]:
+            assert same_bits(row[px[i, 0], :3], fl(g["radiance"]).reshape(-1, 3)[i]), (y, i)
+
+
 def test_thin_lens_ray_kat(oracle, capi):
     """orc_lens_ray against raytracer_win's Camera::GetWorldRay (camera.h:147-173): 200 rays of the
     reference header itself, with the lens offset its glm::circularRand(0.14f) drew for each."""
