@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 2
+#define RT_API_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -159,7 +159,20 @@ typedef struct rt_render_params {
      * finish under the rest of the frame when they are launched first instead of wherever the horizon
      * happens to be; rt_split_bands' cost map tells where that is.  0 = top row first. */
     int32_t first_row;
+    /* A context over several devices (rt_create_multi; ignored otherwise): how the frame is shared, RT_PLAN_*. */
+    int32_t device_plan;
 } rt_render_params;
+
+/* How rt_render shares one frame between the devices of an rt_create_multi context (same image either way). */
+enum {
+    RT_PLAN_AUTO = 0,   /* strips when every device gets at least one (width >= 8 * n_devices), else bands         */
+    RT_PLAN_BANDS = 1,  /* contiguous row bands balanced by a 1/16-resolution cost pre-pass on the first device; the
+                           pre-pass runs (and BLOCKS the caller: render + download + prefix sum) whenever the scene,
+                           the camera or the frame geometry changed since the last plan -- rt_stats.replans counts */
+    RT_PLAN_STRIPS = 2  /* 8-column strips dealt round-robin (col_interleave inside the context): every device gets
+                           the same share of every row, no pre-pass, nothing blocks; measured on one GPU: slowest of
+                           8 parts 1.05x the mean against 1.12x for the bands                                    */
+};
 
 #define RT_STRIP_COLS 8
 
@@ -192,6 +205,8 @@ typedef struct rt_stats {
     double device_kernel_ms[RT_MAX_DEVICES];    /* ... the device time of its trace kernel ...        */
     double device_gather_ms[RT_MAX_DEVICES];    /* ... and of copying its band into the frame         */
     double gather_ms;           /* the slowest of those copies                                       */
+    uint32_t replans;           /* RT_PLAN_BANDS: cost pre-passes this context has run so far (each one blocks)   */
+    int32_t device_plan;        /* RT_PLAN_BANDS or RT_PLAN_STRIPS: what the last frame used                     */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -203,9 +218,9 @@ void rt_destroy(rt_context *ctx);
 
 /* One context over n_devices HIP devices (1..RT_MAX_DEVICES; an id may repeat: its bands then share that
  * device).  Replaces the thread fan-out INSIDE DrawScene (main.cpp:193-227: `partitions` threads fill one
- * shared Bitmap): rt_upload_scene replicates the scene, rt_render cuts the rows into one cost-balanced band per
- * device (1/16-resolution pre-pass on the first device, rt_split_bands), renders them concurrently and
- * assembles the frame on device_ids[0] (peer copies over xGMI), which is where rt_download_framebuffer,
+ * shared Bitmap): rt_upload_scene replicates the scene, rt_render shares the frame between the devices
+ * (rt_render_params.device_plan: 8-column strips dealt round-robin, or cost-balanced row bands), renders the parts
+ * concurrently and assembles the frame on device_ids[0] (peer copies over xGMI), which is where rt_download_framebuffer,
  * rt_pack_framebuffer and rt_framebuffer_device_ptr then find it; rt_get_stats adds per-device kernel and
  * copy times.  Every other call works as on a single-device context, except rt_render_noalloc and
  * col_interleave (RT_ERR_INVALID_ARG).  n_devices == 1 is rt_create. */

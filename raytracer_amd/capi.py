@@ -20,6 +20,7 @@ RT_OUT_RGBA8, RT_OUT_F32X4, RT_OUT_COST = 1, 2, 4
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
 RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2
+RT_PLAN_AUTO, RT_PLAN_BANDS, RT_PLAN_STRIPS = 0, 1, 2
 RT_STRIP_COLS = 8
 RT_MAX_DEVICES = 8
 RT_SCENE_DEFAULT, RT_SCENE_GRID1K, RT_SCENE_GRID16K = 0, 1, 2
@@ -52,7 +53,8 @@ class RenderParams(C.Structure):
                 ("mode", C.c_int32), ("collect_stats", C.c_int32), ("sweep", C.c_int32),
                 ("lens_offsets", C.POINTER(C.c_float)), ("focal_length", C.c_float),
                 ("accumulate", C.c_int32), ("accum_index", C.c_int32),
-                ("col_interleave", C.c_int32), ("col_phase", C.c_int32), ("first_row", C.c_int32)]
+                ("col_interleave", C.c_int32), ("col_phase", C.c_int32), ("first_row", C.c_int32),
+                ("device_plan", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -63,7 +65,8 @@ class Stats(C.Structure):
                 ("sphere_tests_run", C.c_uint64), ("group_tests_run", C.c_uint64), ("exact_tests_run", C.c_uint64),
                 ("n_devices", C.c_uint32), ("device_id", C.c_int32 * RT_MAX_DEVICES), ("device_row_begin", C.c_int32 * RT_MAX_DEVICES),
                 ("device_row_end", C.c_int32 * RT_MAX_DEVICES), ("device_kernel_ms", C.c_double * RT_MAX_DEVICES),
-                ("device_gather_ms", C.c_double * RT_MAX_DEVICES), ("gather_ms", C.c_double)]
+                ("device_gather_ms", C.c_double * RT_MAX_DEVICES), ("gather_ms", C.c_double),
+                ("replans", C.c_uint32), ("device_plan", C.c_int32)]
 
 
 EXPORTS = [
@@ -199,7 +202,7 @@ def stratified_offsets(spp=16, seed=0x16A11CE):
 
 def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, outputs=RT_OUT_RGBA8,
                   mode=RT_MODE_EXACT, stats=False, sweep=0, lens=None, focal_length=0.0, accumulate=None,
-                  interleave=None, first_row=0):
+                  interleave=None, first_row=0, device_plan=RT_PLAN_AUTO):
     """interleave: (n, phase) = render the 8-column strips s with s % n == phase, side by side (multi-GPU);
     lens: spp x 2 lens-plane offsets (thin-lens depth of field) with focal_length; accumulate: k
     (currentSample) for the progressive running mean, None = overwrite."""
@@ -224,6 +227,7 @@ def render_params(width, height, max_depth=5, spp=1, offsets=None, rows=None, ou
     if interleave is not None:
         p.col_interleave, p.col_phase = int(interleave[0]), int(interleave[1])
     p.first_row = int(first_row)
+    p.device_plan = int(device_plan)
     p._keep = (keep, keep_lens)  # keep the arrays alive as long as the struct
     return p
 

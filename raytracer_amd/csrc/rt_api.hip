@@ -46,7 +46,7 @@ struct rt_context {
 
     void *sample_buf = nullptr;       // sample split: one float4 per (sample, pixel)
     size_t sample_bytes = 0;
-    int sample_split = 1;             // RT_AMD_SAMPLE_SPLIT=0 turns it off (A/B)
+    int sample_split = 1;
     void *pack_buf = nullptr;         // staging for the 24-bit download formats
     size_t pack_bytes = 0;
     RtStatsDev *stats_dev = nullptr;
@@ -59,8 +59,20 @@ struct rt_context {
     // parts[0]'s device and one single-device context per entry of device_ids
     std::vector<rt_context *> parts;
     std::vector<int32_t> bounds;      // row bands of the last plan: part i renders [bounds[i], bounds[i+1])
-    struct PlanKey { int32_t w, h, depth, y0, y1, spp, sweep; uint64_t scene_version; } plan_key = {};
+    struct PlanKey {
+        int32_t w, h, depth, y0, y1, spp, sweep;
+        uint64_t scene_version;
+        bool operator==(const PlanKey &o) const     // field by field: the struct has padding bytes
+        {
+            return w == o.w && h == o.h && depth == o.depth && y0 == o.y0 && y1 == o.y1 && spp == o.spp && sweep == o.sweep &&
+                   scene_version == o.scene_version;
+        }
+    } plan_key = {};
     bool have_plan = false;
+    uint32_t replans = 0;             // cost pre-passes run so far (RT_PLAN_BANDS)
+    int last_plan = 0;                // RT_PLAN_BANDS / RT_PLAN_STRIPS of the last frame
+    std::vector<void *> stage[2];     // RT_PLAN_STRIPS: per part, a copy of its planes on the root's device (parts on other devices)
+    std::vector<size_t> stage_bytes[2];
     uint64_t scene_version = 0;       // bumped by rt_upload_scene / rt_set_camera
     std::vector<hipEvent_t> part_done, copy_begin;   // per part: band copied into the frame; its copy began
     hipEvent_t root_ready = nullptr;  // the root stream's work before a render (the caller's, on its stream)
@@ -116,6 +128,16 @@ static int fail(rt_context *ctx, int code, const char *fmt, ...)
             return fail(ctx, RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// The library reads no tuning knobs from the environment.  Three DEBUG switches remain for the test suite and the
+// profiling scripts, and only with RT_AMD_DEBUG=1 set as well: RT_AMD_KERNEL=simple (the straight-transcription kernel as
+// an independent witness), RT_AMD_FAR_FRACTION (sends all / no lanes through dense_sweep) and RT_AMD_REGION_DUMP
+// (profiling builds: wave-cycles by region).
+static const char *debug_env(const char *name)
+{
+    const char *on = getenv("RT_AMD_DEBUG");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 
 static const float kRefPattern[8] = {0.1f, 0.2f, 0.6f, 0.5f, 0.8f, 0.7f, 0.2f, 0.8f};  // main.cpp:202
 
@@ -202,6 +224,34 @@ static hipError_t launch_pack(const RtFrameDev &fr, const uint32_t *rgba, uint32
     return hipGetLastError();
 }
 
+// RT_PLAN_STRIPS, assembly: part `phase` of `n` holds its 8-column strips side by side (w_part columns); column x of it
+// is image column ((x / 8) * n + phase) * 8 + x % 8 (rt_render_params.col_interleave).  One thread per element (a
+// 4-byte RGBA8 word or a 16-byte float4), rows coalesced in 8-element runs on the writing side.
+template <class T>
+__global__ __launch_bounds__(256) void scatter_strips_kernel(T *__restrict__ dst, const T *__restrict__ src, unsigned w_img,
+                                                             unsigned w_part, unsigned rows, unsigned n, unsigned phase)
+{
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (size_t)w_part * rows) return;
+    const unsigned row = (unsigned)(idx / w_part), x = (unsigned)(idx - (size_t)row * w_part);
+    const unsigned xi = (((x >> 3) * n + phase) << 3) | (x & 7u);
+    dst[(size_t)row * w_img + xi] = src[idx];
+}
+
+static hipError_t launch_scatter(void *dst, const void *src, int plane, int w_img, int w_part, int rows, int n, int phase, hipStream_t stream)
+{
+    const size_t elems = (size_t)w_part * (size_t)rows;
+    if (!elems) return hipSuccess;
+    const dim3 grid((unsigned)((elems + 255) / 256)), block(256);
+    if (plane == 0)
+        hipLaunchKernelGGL(scatter_strips_kernel<uint32_t>, grid, block, 0, stream, (uint32_t *)dst, (const uint32_t *)src, (unsigned)w_img,
+                           (unsigned)w_part, (unsigned)rows, (unsigned)n, (unsigned)phase);
+    else
+        hipLaunchKernelGGL(scatter_strips_kernel<float4>, grid, block, 0, stream, (float4 *)dst, (const float4 *)src, (unsigned)w_img,
+                           (unsigned)w_part, (unsigned)rows, (unsigned)n, (unsigned)phase);
+    return hipGetLastError();
+}
+
 static int take_event(rt_context *ctx, hipEvent_t *out)
 {
     if (!ctx->ev_free.empty()) {
@@ -228,19 +278,14 @@ int rt_create(rt_context **out, int device_id)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", device_id, n);
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
-    const char *kern = getenv("RT_AMD_KERNEL");
+    const char *kern = debug_env("RT_AMD_KERNEL");
     ctx->simple_kernel = kern && strcmp(kern, "simple") == 0;
-    if (const char *sp = getenv("RT_AMD_SAMPLE_SPLIT")) ctx->sample_split = atoi(sp) != 0;
-    if (const char *kb = getenv("RT_AMD_LDS_KB")) {       // tuning knob: LDS bytes a workgroup may stage
-        int v = atoi(kb);
-        if (v >= 8 && v <= 160) ctx->lds_budget = v * 1024;
-    }
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->stats_dev, sizeof(RtStatsDev));
     if (e == hipSuccess) e = scratch_for_device(device_id, &ctx->scratch_dev);     // device_id is current here
-    if (e == hipSuccess && getenv("RT_AMD_REGION_DUMP")) e = hipMalloc((void **)&ctx->region_dev, RT_N_REGIONS * sizeof(unsigned long long));
+    if (e == hipSuccess && debug_env("RT_AMD_REGION_DUMP")) e = hipMalloc((void **)&ctx->region_dev, RT_N_REGIONS * sizeof(unsigned long long));
     if (e != hipSuccess) {
         fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e));
         rt_destroy(ctx);
@@ -276,6 +321,13 @@ int rt_create_multi(rt_context **out, const int *device_ids, int n_devices)
                 hipError_t e = hipDeviceEnablePeerAccess(device_ids[i], 0);
                 if (e != hipSuccess) (void)hipGetLastError();       // already enabled
             }
+            // and the other way round: the copies are issued on the part's stream and write into the root's memory
+            can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) {
+                (void)hipSetDevice(device_ids[i]);
+                hipError_t e = hipDeviceEnablePeerAccess(device_ids[0], 0);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
         }
         hipError_t e = hipSetDevice(device_ids[0]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&root->root_ready, hipEventDisableTiming);
@@ -306,6 +358,8 @@ void rt_destroy(rt_context *ctx)
     if (ctx->root_ready) (void)hipEventDestroy(ctx->root_ready);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 2; k++)
+        for (void *p : ctx->stage[k]) if (p) (void)hipFree(p);
     if (ctx->scene_blob) (void)hipFree(ctx->scene_blob);
     for (int i = 0; i < 2; i++)
         if (ctx->own_plane[i]) (void)hipFree(ctx->own_plane[i]);
@@ -479,7 +533,6 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
         groups.push_back(g);
         cur.clear();
     };
-    const bool emitters_apart = !getenv("RT_AMD_NO_EMIT_GROUPS");       // (A/B knob)
     for (size_t k = 0; k < n; k++) {
         const uint32_t i = order[k].second;
         if (!finite[i]) {                   // never hit by anything (dSquared is NaN or r*r is inf): own group
@@ -488,7 +541,7 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
             close();
             continue;
         }
-        if (emitters_apart && emissive[i]) continue;      // below
+        if (emissive[i]) continue;      // below
         if ((int)cur.size() == kMax) close();
         if (!cur.empty()) {
             std::vector<uint32_t> trial = cur;
@@ -503,9 +556,9 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
     std::vector<uint32_t> tail;                                  // at most kMax emissive spheres: no group, no bound
     {
         std::vector<uint32_t> em;
-        for (size_t k = 0; emitters_apart && k < n; k++)
+        for (size_t k = 0; k < n; k++)
             if (finite[order[k].second] && emissive[order[k].second]) em.push_back(order[k].second);
-        if (em.size() <= (size_t)kMax && !getenv("RT_AMD_NO_TAIL")) {
+        if (em.size() <= (size_t)kMax) {
             tail = em;
         } else {
             for (uint32_t i : em) {                              // along the same curve, 8 to a group
@@ -539,7 +592,6 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
         for (int a = 0; a < 3; a++) {
             double sg = (cnt && ext[a] > 0 && std::isfinite(widest)) ? widest / ext[a] : 1.0;
             sg = sg >= 3.0 ? 4.0 : sg >= 1.6 ? 2.0 : 1.0;
-            if (getenv("RT_AMD_ROUND_BOUNDS")) sg = 1.0;       // A/B knob
             out.sigma[a] = (float)sg;
             out.kappa = std::max(out.kappa, (float)sg);
         }
@@ -708,6 +760,11 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         });
         for (size_t i = 0; i < ne; i++) emit[i].order = ord[i];
     }
+    std::vector<RtEmitterDev> emit_sweep(emit.size());
+    for (size_t i = 0; i < emit.size(); i++) {
+        emit_sweep[i] = emit[(size_t)emit[i].order];
+        emit_sweep[i].order = emit[i].order;
+    }
     if (planes.size() > RT_MAX_PLANES)
         return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %zu planes > limit %d", planes.size(), RT_MAX_PLANES);
     if (emit.size() > RT_MAX_EMITTERS)
@@ -735,7 +792,8 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     size_t off_planes = align(off_id + sph_id.size() * sizeof(int32_t));
     size_t off_mats = align(off_planes + planes.size() * sizeof(RtPlaneDev));
     size_t off_emit = align(off_mats + mats.size() * sizeof(rt_material));
-    size_t off_gpairs = align(off_emit + emit.size() * sizeof(RtEmitterDev));
+    size_t off_emit_sweep = align(off_emit + emit.size() * sizeof(RtEmitterDev));
+    size_t off_gpairs = align(off_emit_sweep + emit_sweep.size() * sizeof(RtEmitterDev));
     size_t off_gids = align(off_gpairs + grp.pairs.size() * sizeof(float4));
     size_t off_heads = align(off_gids + grp.ids.size() * sizeof(int32_t));
     size_t off_supers = align(off_heads + grp.heads.size() * sizeof(float4));
@@ -761,6 +819,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     if (!planes.empty()) memcpy(blob.data() + off_planes, planes.data(), planes.size() * sizeof(RtPlaneDev));
     memcpy(blob.data() + off_mats, mats.data(), mats.size() * sizeof(rt_material));
     if (!emit.empty()) memcpy(blob.data() + off_emit, emit.data(), emit.size() * sizeof(RtEmitterDev));
+    if (!emit_sweep.empty()) memcpy(blob.data() + off_emit_sweep, emit_sweep.data(), emit_sweep.size() * sizeof(RtEmitterDev));
     if (!grp.pairs.empty()) memcpy(blob.data() + off_gpairs, grp.pairs.data(), grp.pairs.size() * sizeof(float4));
     if (!grp.ids.empty()) memcpy(blob.data() + off_gids, grp.ids.data(), grp.ids.size() * sizeof(int32_t));
     if (!grp.heads.empty()) memcpy(blob.data() + off_heads, grp.heads.data(), grp.heads.size() * sizeof(float4));
@@ -788,6 +847,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.planes = (const RtPlaneDev *)(base + off_planes);
     ctx->scene.mats = (const rt_material *)(base + off_mats);
     ctx->scene.emit = (const RtEmitterDev *)(base + off_emit);
+    ctx->scene.emit_sweep = (const RtEmitterDev *)(base + off_emit_sweep);
     ctx->scene.n_spheres = (int32_t)geom.size();
     ctx->scene.n_planes = (int32_t)planes.size();
     ctx->scene.n_objects = n;
@@ -816,8 +876,6 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene_grouped.supers_flat = (const float4 *)(base + off_supers_flat);
     ctx->scene_grouped.beam_max_rho = 8.0f;       // (measured: grid-1024 flat from 0.5 to 32; the 16k scene 36.8 ms at 0.5, 36.1 at 2, 33.3 at 8, 32.5 at 32)
     ctx->scene_grouped.beam_max_chord2 = 0.0625f;
-    if (const char *v = getenv("RT_AMD_BEAM_RHO")) ctx->scene_grouped.beam_max_rho = (float)atof(v);        // tuning knobs (A/B);
-    if (const char *v = getenv("RT_AMD_BEAM_CHORD2")) ctx->scene_grouped.beam_max_chord2 = (float)atof(v);  // a negative value turns the beam test off
     {
         // far lanes (rt_sweep_kernel.inc, dense_sweep): the filter keeps a sphere whose centre lies within about
         // sqrt(r^2 + 1.25 * 2^-17 |pos|^2) of a ray's line; once that reaches half (large scenes: a quarter) of the scene's radius the
@@ -833,7 +891,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         // 1080p: 0.25 7.7 ms, 0.5 13.2 -- a wave that keeps a half-far lane walks most of the scene with all its lanes, which
         // takes the longer the larger the scene is, and at lower resolutions that one wave is the frame)
         double fraction = geom.size() <= 2048 ? 0.5 : 0.25;
-        if (const char *v = getenv("RT_AMD_FAR_FRACTION")) fraction = atof(v);
+        if (const char *v = debug_env("RT_AMD_FAR_FRACTION")) fraction = atof(v);
         const double reach = fraction * 0.5 * std::sqrt(diag2);        // of the radius of the box around the spheres
         const double fb = reach * reach / 5.0;                          // allowance^2 = 5 * (2^-19 |pos|^2) = 5 * filter bound
         ctx->scene_grouped.far_bound = (fraction > 0.0 && fb == fb && fb < 1e30 && !geom.empty()) ? (float)fb : INFINITY;
@@ -955,9 +1013,17 @@ static int plan_bands_multi(rt_context *ctx, const rt_render_params *p, int y0, 
     first->cam = low;
     void *keep[2] = {first->bound_plane[0], first->bound_plane[1]};
     first->bound_plane[0] = first->bound_plane[1] = nullptr;
+    (void)drain_events(first, true);                     // the pre-pass is not one of device 0's frames: its kernel time
+    const double keep_total = first->kernel_ms_total, keep_last = first->kernel_ms_last;     // stays out of the totals
+    const uint64_t keep_timed = first->kernels_timed;
     int rc = rt_render(first, &q);
     std::vector<float> plane((size_t)lw * (size_t)lh * 4);
     if (rc == RT_OK) rc = rt_download_framebuffer(first, plane.data(), plane.size() * sizeof(float), RT_FMT_F32X4);
+    (void)drain_events(first, true);
+    first->kernel_ms_total = keep_total;
+    first->kernel_ms_last = keep_last;
+    first->kernels_timed = keep_timed;
+    ctx->replans++;
     first->cam = full;
     first->bound_plane[0] = keep[0];
     first->bound_plane[1] = keep[1];
@@ -981,14 +1047,74 @@ static int plan_bands_multi(rt_context *ctx, const rt_render_params *p, int y0, 
 
 static int render_impl(rt_context *ctx, const rt_render_params *p, const struct NoAllocPlanes *na);
 
+// Queues the frame's parts on their devices; a failure after the first part was queued is handled by the caller
+// (render_multi waits for what was launched).
+static int render_multi_parts(rt_context *ctx, const rt_render_params *p, int y0, int y1, bool strips)
+{
+    const int n = (int)ctx->parts.size();
+    RT_HIP(ctx, hipEventRecord(ctx->root_ready, ctx->stream));
+    for (int i = 0; i < n; i++) {
+        rt_context *part = ctx->parts[(size_t)i];
+        const int b0 = strips ? y0 : ctx->bounds[(size_t)i], b1 = strips ? y1 : ctx->bounds[(size_t)i + 1];
+        const int w_part = strips ? rt_interleaved_count(p->width, n, i) : p->width;
+        RT_HIP(ctx, hipSetDevice(part->device));
+        RT_HIP(ctx, hipStreamWaitEvent(part->stream, ctx->root_ready, 0));
+        RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));     // (an empty part: begin == done)
+        if (b1 > b0 && w_part > 0) {
+            rt_render_params q = *p;
+            q.row_begin = b0;
+            q.row_end = b1;
+            q.first_row = (p->first_row > b0 && p->first_row < b1) ? p->first_row : 0;
+            q.col_interleave = strips ? n : 0;
+            q.col_phase = strips ? i : 0;
+            int rc = render_impl(part, &q, nullptr);
+            if (rc) return fail(ctx, rc, "device %d, rows [%d,%d): %s", part->device, b0, b1, part->err);
+            RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));
+            for (int k = 0; k < 2; k++) {
+                if (!ctx->cur_plane[k]) continue;
+                const size_t bpp = k ? 16 : 4, bytes = (size_t)w_part * (size_t)(b1 - b0) * bpp;
+                if (!strips) {
+                    char *dst = (char *)ctx->cur_plane[k] + (size_t)p->width * (size_t)(b0 - y0) * bpp;
+                    if (part->device == ctx->device)
+                        RT_HIP(ctx, hipMemcpyAsync(dst, part->cur_plane[k], bytes, hipMemcpyDeviceToDevice, part->stream));
+                    else
+                        RT_HIP(ctx, hipMemcpyPeerAsync(dst, ctx->device, part->cur_plane[k], part->device, bytes, part->stream));
+                } else if (part->device == ctx->device) {
+                    // same device: the strips go straight to their columns (parts write disjoint columns)
+                    RT_HIP(ctx, launch_scatter(ctx->cur_plane[k], part->cur_plane[k], k, p->width, w_part, b1 - b0, n, i, part->stream));
+                } else {
+                    // another device: one contiguous peer copy into the root device's staging copy of the part; the root's
+                    // stream puts the strips in place once the copy is done (below)
+                    RT_HIP(ctx, hipMemcpyPeerAsync(ctx->stage[k][(size_t)i], ctx->device, part->cur_plane[k], part->device, bytes, part->stream));
+                }
+            }
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->part_done[(size_t)i], part->stream));
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) {
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->part_done[(size_t)i], 0));
+        rt_context *part = ctx->parts[(size_t)i];
+        if (!strips || part->device == ctx->device) continue;
+        const int w_part = rt_interleaved_count(p->width, n, i);
+        for (int k = 0; k < 2; k++)
+            if (ctx->cur_plane[k] && w_part > 0 && y1 > y0)
+                RT_HIP(ctx, launch_scatter(ctx->cur_plane[k], ctx->stage[k][(size_t)i], k, p->width, w_part, y1 - y0, n, i, ctx->stream));
+    }
+    return RT_OK;
+}
+
 static int render_multi(rt_context *ctx, const rt_render_params *p)
 {
+    ctx->have_frame = false;          // until this render is queued: a failure below leaves no frame, not the previous one's description
     if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: params NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
     if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: bad image size %dx%d", p->width, p->height);
     if (p->col_interleave > 1)
-        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: a context over several devices shares the rows itself; col_interleave is for one context per device");
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: a context over several devices shares the frame itself (device_plan); col_interleave is for one context per device");
+    if (p->device_plan != RT_PLAN_AUTO && p->device_plan != RT_PLAN_BANDS && p->device_plan != RT_PLAN_STRIPS)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown device_plan %d", p->device_plan);
     int y0 = p->row_begin, y1 = p->row_end;
     if (y0 == 0 && y1 == 0) y1 = p->height;
     if (y0 < 0 || y1 > p->height || y0 > y1)
@@ -996,61 +1122,66 @@ static int render_multi(rt_context *ctx, const rt_render_params *p)
     const int n = (int)ctx->parts.size();
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
 
-    // 1. the plan: kept while scene, camera and frame geometry stay (and for the whole of a progressive
-    //    accumulation, whose running mean lives in each device's band)
-    const rt_context::PlanKey key = {p->width, p->height, p->max_depth, y0, y1, p->spp, p->sweep, ctx->scene_version};
-    const bool continuing = p->accumulate && p->accum_index > 0 && ctx->have_plan && ctx->plan_key.w == key.w &&
-                            ctx->plan_key.h == key.h && ctx->plan_key.y0 == key.y0 && ctx->plan_key.y1 == key.y1;
-    if (!continuing && !(ctx->have_plan && memcmp(&key, &ctx->plan_key, sizeof key) == 0)) {
-        ctx->have_plan = false;
-        int rc = plan_bands_multi(ctx, p, y0, y1);
-        if (rc) return rc;
-        memset(&ctx->plan_key, 0, sizeof ctx->plan_key);
-        ctx->plan_key = key;
-        ctx->have_plan = true;
+    // 1. the plan.  Strips need none (and nothing blocks).  Bands: kept while scene, camera and frame geometry stay,
+    //    and for the whole of a progressive accumulation, whose running mean lives in each device's part (a running
+    //    mean also keeps the KIND of plan its first frame had)
+    const bool continuing = p->accumulate && p->accum_index > 0 && ctx->last_plan != 0;
+    bool strips = p->device_plan == RT_PLAN_STRIPS || (p->device_plan == RT_PLAN_AUTO && p->width >= RT_STRIP_COLS * n);
+    if (continuing) strips = ctx->last_plan == RT_PLAN_STRIPS;
+    // (fewer strips than devices: the devices past the last strip render nothing)
+    if (!strips) {
+        const rt_context::PlanKey key = {p->width, p->height, p->max_depth, y0, y1, p->spp, p->sweep, ctx->scene_version};
+        const bool same_bands = continuing && ctx->have_plan && ctx->plan_key.w == key.w && ctx->plan_key.h == key.h &&
+                                ctx->plan_key.y0 == key.y0 && ctx->plan_key.y1 == key.y1;
+        if (!same_bands && !(ctx->have_plan && key == ctx->plan_key)) {
+            ctx->have_plan = false;
+            int rc = plan_bands_multi(ctx, p, y0, y1);
+            if (rc) return rc;
+            ctx->plan_key = key;
+            ctx->have_plan = true;
+        }
     }
 
-    // 2. the frame on the first device
+    // 2. the frame on the first device (and, for strips rendered on other devices, a staging copy of each part)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)p->width * (size_t)(y1 - y0);
     ctx->cur_plane[0] = ctx->cur_plane[1] = nullptr;
-    for (int i = 0; i < 2; i++) {
-        if (!(outputs & (i ? RT_OUT_F32X4 : RT_OUT_RGBA8))) continue;
-        const size_t need = px * (i ? 16 : 4);
-        int rc = ensure_plane(ctx, i, need ? need : 16);
+    for (int k = 0; k < 2; k++) {
+        if (!(outputs & (k ? RT_OUT_F32X4 : RT_OUT_RGBA8))) continue;
+        const size_t need = px * (k ? 16 : 4);
+        int rc = ensure_plane(ctx, k, need ? need : 16);
         if (rc) return rc;
+        if (!strips) continue;
+        ctx->stage[k].resize((size_t)n, nullptr);
+        ctx->stage_bytes[k].resize((size_t)n, 0);
+        for (int i = 0; i < n; i++) {
+            if (ctx->parts[(size_t)i]->device == ctx->device) continue;
+            const size_t bytes = (size_t)rt_interleaved_count(p->width, n, i) * (size_t)(y1 - y0) * (k ? 16 : 4);
+            if (ctx->stage_bytes[k][(size_t)i] >= bytes) continue;
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->stage[k][(size_t)i]) RT_HIP(ctx, hipFree(ctx->stage[k][(size_t)i]));
+            ctx->stage[k][(size_t)i] = nullptr;
+            ctx->stage_bytes[k][(size_t)i] = 0;
+            RT_HIP(ctx, hipMalloc(&ctx->stage[k][(size_t)i], bytes));
+            ctx->stage_bytes[k][(size_t)i] = bytes;
+        }
     }
 
-    // 3. bands: each device renders on its own stream, after whatever is already on the root's
-    RT_HIP(ctx, hipEventRecord(ctx->root_ready, ctx->stream));
-    for (int i = 0; i < n; i++) {
-        rt_context *part = ctx->parts[(size_t)i];
-        const int b0 = ctx->bounds[(size_t)i], b1 = ctx->bounds[(size_t)i + 1];
-        RT_HIP(ctx, hipSetDevice(part->device));
-        RT_HIP(ctx, hipStreamWaitEvent(part->stream, ctx->root_ready, 0));
-        RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));     // (an empty band: begin == done)
-        if (b1 > b0) {
-            rt_render_params q = *p;
-            q.row_begin = b0;
-            q.row_end = b1;
-            q.first_row = (p->first_row > b0 && p->first_row < b1) ? p->first_row : 0;
-            int rc = render_impl(part, &q, nullptr);
-            if (rc) return fail(ctx, rc, "device %d, rows [%d,%d): %s", part->device, b0, b1, part->err);
-            RT_HIP(ctx, hipEventRecord(ctx->copy_begin[(size_t)i], part->stream));
-            for (int k = 0; k < 2; k++) {
-                if (!ctx->cur_plane[k]) continue;
-                const size_t bpp = k ? 16 : 4, bytes = (size_t)p->width * (size_t)(b1 - b0) * bpp;
-                char *dst = (char *)ctx->cur_plane[k] + (size_t)p->width * (size_t)(b0 - y0) * bpp;
-                if (part->device == ctx->device)
-                    RT_HIP(ctx, hipMemcpyAsync(dst, part->cur_plane[k], bytes, hipMemcpyDeviceToDevice, part->stream));
-                else
-                    RT_HIP(ctx, hipMemcpyPeerAsync(dst, ctx->device, part->cur_plane[k], part->device, bytes, part->stream));
-            }
-        }
-        RT_HIP(ctx, hipEventRecord(ctx->part_done[(size_t)i], part->stream));
+    // 3. the parts: each device renders on its own stream, after whatever is already on the root's
+    if (strips) {
+        ctx->bounds.assign((size_t)n + 1, y1);          // (reported per device by rt_get_stats: every device renders all rows)
+        ctx->bounds[0] = y0;
     }
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < n; i++) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->part_done[(size_t)i], 0));
+    {
+        int rc = render_multi_parts(ctx, p, y0, y1, strips);
+        if (rc) {
+            // nothing is left running behind a failed render: wait for the parts that were queued
+            for (rt_context *part : ctx->parts)
+                if (hipSetDevice(part->device) == hipSuccess) (void)hipStreamSynchronize(part->stream);
+            (void)hipSetDevice(ctx->device);
+            return rc;
+        }
+    }
 
     RtFrameDev fr = {};
     fr.rgba8 = (uint32_t *)ctx->cur_plane[0];
@@ -1062,6 +1193,7 @@ static int render_multi(rt_context *ctx, const rt_render_params *p)
     fr.spp = p->spp;
     ctx->frame = fr;
     ctx->have_frame = true;
+    ctx->last_plan = strips ? RT_PLAN_STRIPS : RT_PLAN_BANDS;
     ctx->last_outputs = outputs & (RT_OUT_RGBA8 | RT_OUT_F32X4);
     ctx->stats_pending = p->collect_stats != 0;
     ctx->gather_pending = true;
@@ -1412,9 +1544,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
         for (size_t i = 0; i < ctx->parts.size(); i++) {
             rt_context *part = ctx->parts[i];
             total.device_id[i] = part->device;
-            total.device_row_begin[i] = ctx->bounds[i];
-            total.device_row_end[i] = ctx->bounds[i + 1];
-            if (ctx->bounds[i + 1] == ctx->bounds[i]) continue;            // an empty band rendered nothing
+            const bool strips = ctx->last_plan == RT_PLAN_STRIPS;
+            const int rb = strips ? ctx->bounds[0] : ctx->bounds[i], re = strips ? ctx->bounds.back() : ctx->bounds[i + 1];
+            total.device_row_begin[i] = rb;
+            total.device_row_end[i] = re;
+            if (re == rb || (strips && rt_interleaved_count(ctx->frame.width, (int)ctx->parts.size(), (int)i) <= 0)) continue;   // an empty part rendered nothing
             rt_stats st = {};
             if ((rc = rt_get_stats(part, &st))) return fail(ctx, rc, "device %d: %s", part->device, part->err);
             total.primary_rays += st.primary_rays;
@@ -1443,6 +1577,8 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
         }
         if (!ctx->gather_pending) total.gather_ms = ctx->gather_ms_last;
         ctx->gather_ms_last = total.gather_ms;
+        total.replans = ctx->replans;
+        total.device_plan = ctx->last_plan;
         *out = total;
         return RT_OK;
     }

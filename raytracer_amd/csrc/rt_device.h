@@ -54,8 +54,9 @@ struct RtEmitterDev {
     int32_t id;           // list index
     int32_t is_plane;
     int32_t sphere_slot;  // index into geom[] when the emitter is a sphere, else -1
-    int32_t order;        // sweep order: entry i names the emitter whose shadow ray is swept i-th (emitters
-                          // that lie in similar directions share a sweep; light summation stays in list order)
+    int32_t order;        // emit[]: entry i names the emitter whose shadow ray is swept i-th (emitters that lie in similar
+                          // directions share a sweep; light summation stays in list order).  emit_sweep[]: the emitters
+                          // in that sweep order, `order` = the record's own index in emit[] (its bit in the lit mask)
     float radius;         // |radius| of a sphere emitter, +inf for a plane (grouped sweep: decided shadow rays)
 };
 
@@ -66,6 +67,7 @@ struct RtSceneDev {
     const RtPlaneDev *planes;
     const rt_material *mats;
     const RtEmitterDev *emit;
+    const RtEmitterDev *emit_sweep;   // the same records in sweep order (one scalar load per shadow ray instead of two dependent ones)
     int32_t n_spheres, n_planes, n_objects, n_emit;
     int32_t n_pairs;      // pair records in `pairs`: ceil(n_spheres/2) flat, 8*n_groups grouped
     const float4 *heads;  // grouped layout only: bounding spheres of the groups ...

@@ -30,17 +30,6 @@ __device__ __forceinline__ V3 normalize(V3 v)
     float inv = 1.0f / sqrtf(dot(v, v));
     return v * inv;
 }
-#ifdef RT_KO_NORM1
-__device__ __forceinline__ V3 normalize_ko(V3 v) { float inv = __builtin_amdgcn_rsqf(dot(v, v)); return v * inv; }
-#define RT_NORMALIZE1 normalize_ko
-#else
-#define RT_NORMALIZE1 normalize
-#endif
-#ifdef RT_KO_NORM2
-#define RT_NORMALIZE2(v) (v)
-#else
-#define RT_NORMALIZE2(v) normalize(v)
-#endif
 __device__ __forceinline__ V3 reflect(V3 i, V3 n)
 {
     float d = dot(n, i);

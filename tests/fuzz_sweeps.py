@@ -128,7 +128,7 @@ def main():
         return 0
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "simple.txt")
-        env = dict(os.environ, RT_AMD_KERNEL="simple")
+        env = dict(os.environ, RT_AMD_KERNEL="simple", RT_AMD_DEBUG="1")
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--scenes", str(args.scenes), "--seed", str(args.seed),
                                "--child", path], env=env)
         simple = open(path).read().split()

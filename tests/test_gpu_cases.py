@@ -399,8 +399,10 @@ def test_grouped_sweep_is_bit_identical(capi, gpu_ctx, scene, size, depth, spp):
 @pytest.mark.parametrize("fraction", ["1e-9", "0.02", "0"])
 def test_far_lanes_dense_sweep_is_bit_identical(capi, gpu_ctx, fraction, monkeypatch):
     """The grouped sweep hands lanes far from the origin to dense_sweep (every sphere, one ray at a time across
-    the wave).  RT_AMD_FAR_FRACTION, read when a scene is uploaded, moves the threshold: 1e-9 sends every lane
-    that way, 0.02 a mix of lanes within most waves, 0 none; each must give the flat sweep's bits."""
+    the wave).  The debug switch RT_AMD_FAR_FRACTION (with RT_AMD_DEBUG=1), read when a scene is uploaded, moves the
+    threshold: 1e-9 sends every lane that way, 0.02 a mix of lanes within most waves, 0 none; each must give the flat
+    sweep's bits."""
+    monkeypatch.setenv("RT_AMD_DEBUG", "1")
     for scene, (w, h), depth, spp in (("grid1k", (480, 270), 5, 4), ("grid16k", (320, 180), 3, 1)):
         kind = {"grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[scene]
         objs, cam = capi.make_scene(kind, w, h)
@@ -526,6 +528,12 @@ def test_fuzz_sweeps_agree():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "16/16 scenes identical" in r.stdout
+    # and six more with the CPU oracle as a fourth opinion, so that the suite's fuzz is not only a comparison of
+    # this library with itself (hundreds of scenes run this way are logged under profiles/)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_sweeps.py"), "--scenes", "6", "--seed", "4077", "--cpu"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "6/6 scenes identical" in r.stdout and "CPU checker" in r.stdout
 
 
 def test_horizon_and_degenerate_rays(capi, oracle, gpu_ctx):
@@ -554,13 +562,15 @@ def test_horizon_and_degenerate_rays(capi, oracle, gpu_ctx):
 
 
 def test_simple_kernel_agrees(capi, gpu_ctx):
-    """The straight-transcription kernel (RT_AMD_KERNEL=simple) and the sweep kernel agree bit for
+    """The straight-transcription kernel (debug switch RT_AMD_KERNEL=simple with RT_AMD_DEBUG=1) and the sweep kernel agree bit for
     bit -- an independent check of the filter's soundness on a dense scene."""
     os.environ["RT_AMD_KERNEL"] = "simple"
+    os.environ["RT_AMD_DEBUG"] = "1"
     try:
         simple = capi.Context(0)
     finally:
         del os.environ["RT_AMD_KERNEL"]
+        del os.environ["RT_AMD_DEBUG"]
     w, h = 1280, 720
     objs, cam = capi.make_scene(capi.RT_SCENE_GRID1K, w, h)
     a = render_gpu(capi, gpu_ctx, objs, cam, w, h, 8, 1)
@@ -613,49 +623,87 @@ def test_camera_sweep_pipeline(capi, oracle, gpu_ctx, tmp_path):
 @pytest.mark.parametrize("scene,size,depth,spp,n", [("grid1k", (1000, 613), 5, 4, 2), ("grid1k", (640, 360), 8, 1, 5),
                                                     ("default", (323, 200), 5, 4, 8), ("grid1k", (96, 3), 5, 1, 8)])
 def test_multi_device_context(capi, gpu_ctx, scene, size, depth, spp, n):
-    """rt_create_multi with the same device listed n times (n streams on one GPU: SURVEY.md 4, item 5): the
-    assembled frame -- radiance bits, per-pixel ray counts, 8-bit image -- and the ray counters equal the
-    single-device context's; the bands tile the rows; per-device times are reported; and the plan is kept
-    between renders of the same view."""
+    """rt_create_multi with the same device listed n times (n streams on one GPU: SURVEY.md 4, item 5), both ways of
+    sharing a frame (RT_PLAN_BANDS, RT_PLAN_STRIPS): the assembled frame -- radiance bits, per-pixel ray counts, 8-bit
+    image -- and the ray counters equal the single-device context's; the parts tile the frame; per-device times are
+    reported; the band plan is kept between renders of the same view (rt_stats.replans) and strips never plan."""
     w, h = size
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K}[scene]
     objs, cam = capi.make_scene(kind, w, h)
     gpu_ctx.upload_scene(objs, cam)
-    p = capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, stats=True)
-    gpu_ctx.render(p)
+    single = capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, stats=True)
+    gpu_ctx.render(single)
     want = gpu_ctx.download(capi.RT_FMT_RGB8, w, h), gpu_ctx.download(capi.RT_FMT_F32X4, w, h), gpu_ctx.stats()
+    objs2, cam2 = capi.make_scene(kind, w, h, frame=40) if scene != "default" else (objs, capi.camera_init((1, 5, 9), (-.1, -.7, -1), 50.0, w, h))
+    gpu_ctx.set_camera(cam2)
+    gpu_ctx.render(single)
+    want2 = gpu_ctx.download(capi.RT_FMT_F32X4, w, h)
+    gpu_ctx.set_camera(cam)
     multi = capi.Context(devices=[0] * n)
     try:
         multi.upload_scene(objs, cam)
-        for _ in range(2):
+        replans = 0
+        for plan in (capi.RT_PLAN_BANDS, capi.RT_PLAN_STRIPS, capi.RT_PLAN_AUTO):
+            p = capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, stats=True, device_plan=plan)
+            strips = plan == capi.RT_PLAN_STRIPS or (plan == capi.RT_PLAN_AUTO and w >= 8 * n)
+            if not strips:
+                replans += 1                                      # one pre-pass for the two identical renders
+            for _ in range(2):
+                multi.render(p)
+                assert np.array_equal(multi.download(capi.RT_FMT_RGB8, w, h), want[0])
+                assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), want[1].view(np.uint32))
+                st = multi.stats()
+                for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit"):      # (tests executed depend on how pixels fall into waves)
+                    assert st[k] == want[2][k], (k, plan)
+                assert st["n_devices"] == n and st["device_id"][:n] == [0] * n
+                assert st["device_plan"] == (capi.RT_PLAN_STRIPS if strips else capi.RT_PLAN_BANDS) and st["replans"] == replans
+                b0, b1 = st["device_row_begin"][:n], st["device_row_end"][:n]
+                if strips:
+                    assert b0 == [0] * n and b1 == [h] * n
+                    busy = [capi.interleaved_count(w, n, i) > 0 for i in range(n)]
+                else:
+                    assert b0[0] == 0 and b1[-1] == h and all(b1[i] == b0[i + 1] for i in range(n - 1)) and all(b1[i] >= b0[i] for i in range(n))
+                    busy = [b1[i] > b0[i] for i in range(n)]
+                assert st["kernel_ms"] == max(st["device_kernel_ms"][:n]) and st["gather_ms"] == max(st["device_gather_ms"][:n])
+                assert all(st["device_kernel_ms"][i] > 0 for i in range(n) if busy[i])
+            # a new camera: the bands are planned again (once), the strips are not; still the single-device frame
+            multi.set_camera(cam2)
             multi.render(p)
-            assert np.array_equal(multi.download(capi.RT_FMT_RGB8, w, h), want[0])
-            assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), want[1].view(np.uint32))
-            st = multi.stats()
-            for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit"):      # (tests executed depend on how rows fall into waves)
-                assert st[k] == want[2][k], k
-            assert st["n_devices"] == n and st["device_id"][:n] == [0] * n
-            b0, b1 = st["device_row_begin"][:n], st["device_row_end"][:n]
-            assert b0[0] == 0 and b1[-1] == h and all(b1[i] == b0[i + 1] for i in range(n - 1)) and all(b1[i] >= b0[i] for i in range(n))
-            assert st["kernel_ms"] == max(st["device_kernel_ms"][:n]) and st["gather_ms"] == max(st["device_gather_ms"][:n])
-            assert all(st["device_kernel_ms"][i] > 0 for i in range(n) if b1[i] > b0[i])
-        # a new camera: a new plan, still the single-device frame
-        objs2, cam2 = capi.make_scene(kind, w, h, frame=40) if scene != "default" else (objs, capi.camera_init((1, 5, 9), (-.1, -.7, -1), 50.0, w, h))
-        multi.set_camera(cam2)
-        gpu_ctx.set_camera(cam2)
-        multi.render(p)
-        gpu_ctx.render(p)
-        assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), gpu_ctx.download(capi.RT_FMT_F32X4, w, h).view(np.uint32))
-        # a row range, the BMP body, and what a context over several devices does not do
-        rows = (h // 3, h - 1) if h > 8 else (1, 2)
-        multi.render(capi.render_params(w, h, depth, spp, rows=rows))
-        gpu_ctx.render(capi.render_params(w, h, depth, spp, rows=rows))
-        assert np.array_equal(multi.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]), gpu_ctx.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]))
+            if not strips:
+                replans += 1
+            assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), want2.view(np.uint32))
+            assert multi.stats()["replans"] == replans
+            multi.set_camera(cam)
+            if not strips:
+                replans += 1                                      # (back to the first view: planned again by the next round)
+            # a row range and the BMP body
+            rows = (h // 3, h - 1) if h > 8 else (1, 2)
+            multi.render(capi.render_params(w, h, depth, spp, rows=rows, device_plan=plan))
+            gpu_ctx.render(capi.render_params(w, h, depth, spp, rows=rows))
+            assert np.array_equal(multi.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]), gpu_ctx.download(capi.RT_FMT_BMP_BODY, w, rows[1] - rows[0]))
+            replans = multi.stats()["replans"]
+        # progressive accumulation over several devices (DrawSceneOptions::devices with frames > 1): each part keeps its
+        # share of the running mean; the assembled mean equals the single-device one after every frame
+        for plan in (capi.RT_PLAN_BANDS, capi.RT_PLAN_STRIPS):
+            for k in range(3):
+                lens = _circular_lens(spp, 100 + k)
+                kw = dict(outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, lens=lens, focal_length=9.0, accumulate=k)
+                multi.render(capi.render_params(w, h, depth, spp, device_plan=plan, **kw))
+                gpu_ctx.render(capi.render_params(w, h, depth, spp, **kw))
+                assert np.array_equal(multi.download(capi.RT_FMT_F32X4, w, h).view(np.uint32), gpu_ctx.download(capi.RT_FMT_F32X4, w, h).view(np.uint32)), (plan, k)
+                assert np.array_equal(multi.download(capi.RT_FMT_RGB8, w, h), gpu_ctx.download(capi.RT_FMT_RGB8, w, h))
+        # what a context over several devices does not do; a failed render leaves no frame behind
         with pytest.raises(capi.RtError) as e:
             multi.render(capi.render_params(w, h, depth, spp, interleave=(2, 0)))
         assert e.value.code == capi.RT_ERR_INVALID_ARG
         with pytest.raises(capi.RtError) as e:
-            multi.render_noalloc(p, 16, 16, 16, 16)
+            multi.stats()
+        assert e.value.code == capi.RT_ERR_NO_FRAME
+        with pytest.raises(capi.RtError) as e:
+            multi.render(capi.render_params(w, h, depth, spp, device_plan=7))
+        assert e.value.code == capi.RT_ERR_INVALID_ARG
+        with pytest.raises(capi.RtError) as e:
+            multi.render_noalloc(single, 16, 16, 16, 16)
         assert e.value.code == capi.RT_ERR_INVALID_ARG
     finally:
         multi.close()
@@ -668,6 +716,34 @@ def test_multi_device_errors(capi):
     assert capi.lib.rt_create_multi(C.byref(h), ids, 0) == capi.RT_ERR_INVALID_ARG
     assert capi.lib.rt_create_multi(C.byref(h), None, 2) == capi.RT_ERR_INVALID_ARG
     assert capi.lib.rt_create_multi(C.byref(h), (C.c_int * 9)(*([0] * 9)), 9) == capi.RT_ERR_INVALID_ARG
+
+
+def test_camera_sweep_frame_parallel_two_ranks(tmp_path):
+    """Config 5's other half: tools/camera_sweep.py deals the frames of the orbit to the ranks (frame f to rank f mod N,
+    the fan-out of main.cpp:193-227 applied to frames) with no exchange at all.  Two ranks sharing GPU 0 write between
+    them exactly the files one rank writes, byte for byte."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "tools", "camera_sweep.py"), "--frames", "6", "--total-frames", "24", "--width", "320",
+              "--height", "180", "--scene", "grid1k"]
+    one_dir, two_dir = tmp_path / "one", tmp_path / "two"
+    one_dir.mkdir()
+    two_dir.mkdir()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(common + ["--out", str(one_dir)], capture_output=True, text=True, timeout=170, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    procs = [subprocess.Popen(common + ["--out", str(two_dir)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root,
+                              env=dict(env, RANK=str(k), WORLD_SIZE="2", LOCAL_RANK=str(k))) for k in range(2)]
+    outs = [p.communicate(timeout=170) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]) for so, _ in outs]
+    assert sorted(ln["rank"] for ln in lines) == [0, 1] and all(ln["world"] == 2 and ln["frames"] == 3 for ln in lines)
+    names = sorted(os.listdir(one_dir))
+    assert names == ["frame_%04d.bmp" % f for f in range(6)] and sorted(os.listdir(two_dir)) == names
+    for name in names:
+        assert open(one_dir / name, "rb").read() == open(two_dir / name, "rb").read(), name
 
 
 @pytest.mark.parametrize("plan", ["bands", "strips"])

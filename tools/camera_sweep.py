@@ -30,7 +30,7 @@ def main():
     from raytracer_amd import capi, sweep
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())   # (ranks may share a GPU: rehearsals, tests)
     torch.cuda.set_device(local)
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
     mine = list(range(rank, args.frames, world))

@@ -5,7 +5,7 @@
 # usage (GPU box): bash tools/region_profile.sh [bench.py options] > gpurun_out/regions.txt
 set -e
 LIB=${RT_REGION_LIB:-$PWD/raytracer_amd/librt_amd_regions.so}
-RT_AMD_LIB=$LIB RT_AMD_REGION_DUMP=1 timeout -k 10 200 python bench.py --no-cpu --steps 1 --warmup 0 "$@" 2>&1 >/dev/null | grep "rt region cycles" | grep -v "cycles: 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0" | tail -1 | python3 -c '
+RT_AMD_LIB=$LIB RT_AMD_DEBUG=1 RT_AMD_REGION_DUMP=1 timeout -k 10 200 python bench.py --no-cpu --steps 1 --warmup 0 "$@" 2>&1 >/dev/null | grep "rt region cycles" | grep -v "cycles: 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0" | tail -1 | python3 -c '
 import sys
 names = ["ray generation", "primary: super-group bounds", "primary: group bounds", "primary: pair records (filter + exact tests)", "primary: planes, finish",
          "hit point, normal, material, reflect", "shadow-ray set-up", "segment: super-group bounds", "segment: group bounds",
