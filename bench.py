@@ -41,6 +41,29 @@ FLOP_PER_SPHERE_TEST = 15       # 3 sub + 5 (dot) + 5 (dot) + mu
 FLOP_PER_PLANE_TEST = 5
 
 
+def profiled_counters(path, kernel):
+    """{counter: value per launch}, scratch bytes of the profiled kernel, from a committed rocprofv3 PMC summary
+    (tools/pmc_profile.sh / tools/pmc_instmix.sh) -- ({}, None) when the file or the kernel is not there."""
+    rows, on, scratch = {}, False, None
+    try:
+        for line in open(path):
+            if line.startswith('"# ') or line.startswith("# "):
+                if "vgpr,agpr" in line:
+                    if on:
+                        scratch = int(line.split("=")[1].split(",")[4])
+                else:
+                    on = kernel in line
+            elif on and "," in line:
+                k, v = line.split(",")[:2]
+                try:
+                    rows[k] = float(v)
+                except ValueError:
+                    pass
+    except (OSError, ValueError, IndexError):
+        return {}, None
+    return rows, scratch
+
+
 def profiled_traffic(path, kernel):
     """(bytes per launch, scratch bytes of the profiled kernel, VALU busy fraction) from a committed rocprofv3 PMC summary of
     this same command (tools/pmc_profile.sh), plus the VALU pipes' busy fraction: FETCH_SIZE and WRITE_SIZE are in KiB; MI355X_MICROARCH.md's
@@ -375,6 +398,8 @@ def main():
                          "algorithmic_flop_per_launch": int(my_flop),
                          "kernel": "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)",
                          "brute_force_equivalent_tflops": (brute_flop / (k0_ms * 1e-3)) / 1e12 if k0_ms > 0 else 0.0,
+                         # the framebuffer is the only HBM traffic the algorithm asks for: 4 B per pixel per launch
+                         "hbm_write_gbps": (band.numel() * 4 / (k0_ms * 1e-3)) / 1e9 if k0_ms > 0 else 0.0,
                          "lanes_note": None if n_lanes == 1 else "kernel_ms is per launch with %d frames in flight: launches overlap on "
                                        "the device, so it overstates the time a launch would take alone" % n_lanes,
                          "note": "15 FLOP x (ray,sphere) and (ray,group) tests EXECUTED + 5 FLOP x rays x planes; for the "
@@ -383,15 +408,15 @@ def main():
         }
         # committed rocprofv3 summaries by workload: (file, kernel name in the trace, translation unit, mangled template arguments)
         profiled = {
-            ("grid1k", 3840, 2160, 5, 4, "exact", True): ("current_headline.csv", "trace_sweep_kernel<false, false, false, 6, false, 1>", "rt_sweep_grouped", "ILb0ELb0ELb0ELi6ELb0ELi1E"),
-            ("grid1k", 3840, 2160, 5, 4, "exact", False): ("current_headline.csv", "trace_sweep_kernel<false, true, false, 6, false, 0>", "rt_sweep_compact", "ILb0ELb1ELb0ELi6ELb0ELi0E"),
-            ("grid16k", 3840, 2160, 5, 1, "exact", True): ("current_grid16k.csv", "trace_sweep_kernel<false, false, false, 6, false, 2>", "rt_sweep_grouped3", "ILb0ELb0ELb0ELi6ELb0ELi2E"),
+            ("grid1k", 3840, 2160, 5, 4, "exact", True): ("headline_pmc.csv", "trace_sweep_kernel<false, false, false, 6, false, 1>", "rt_sweep_grouped", "ILb0ELb0ELb0ELi6ELb0ELi1E"),
+            ("grid1k", 3840, 2160, 5, 4, "exact", False): ("headline_pmc.csv", "trace_sweep_kernel<false, true, false, 6, false, 0>", "rt_sweep_compact", "ILb0ELb1ELb0ELi6ELb0ELi0E"),
+            ("grid16k", 3840, 2160, 5, 1, "exact", True): ("grid16k_pmc.csv", "trace_sweep_kernel<false, false, false, 6, false, 2>", "rt_sweep_grouped3", "ILb0ELb0ELb0ELi6ELb0ELi2E"),
         }.get((args.scene, W, H, args.depth, args.spp, args.mode, bool(grouped)))
         if world == 1 and profiled:
             # not measurable from inside this process (PMC counters need rocprofv3 around it): taken from the
             # committed rocprofv3 summary of this same command, and only while the kernel is the one profiled
             # (same private-segment size as the build that ships: raytracer_amd/kernel_resources.json)
-            prof = os.path.join(ROOT, "profiles", "r2", profiled[0])
+            prof = os.path.join(ROOT, "profiles", "r3", profiled[0])
             tag = profiled[1]
             traffic, prof_scratch, valu_busy = profiled_traffic(prof, tag)
             built = built_scratch_bytes(profiled[2], profiled[3])
@@ -404,6 +429,22 @@ def main():
                                                  "side, uncorrected: mostly 4-byte private-memory accesses, a width the guide calls uncalibrated); "
                                                  "profiled kernel scratch %s B, built kernel %s B%s" % (prof_scratch, built, "" if same else
                                                  " -- they differ or one is unknown, so the profiled figure is withheld"))
+            # What the VALUs EXECUTED, as opposed to what the tests were worth: SQ_INSTS_VALU_FLOPS_FP32 of the committed
+            # instruction-mix pass of this same command (tools/pmc_instmix.sh; the counter counts 1 / 2 / 4 per wave-instruction
+            # for add or mul / fma or packed add or mul / packed fma -- calibrated in the same file -- so x 64 lanes = FLOP,
+            # idle lanes included), under the same same-build guard as `traffic`.
+            mix, mix_scratch = profiled_counters(os.path.join(ROOT, "profiles", "r3", profiled[0].replace("_pmc.csv", "_instmix.csv")), tag)
+            if mix.get("SQ_INSTS_VALU_FLOPS_FP32") and built is not None and mix_scratch == built and k0_ms > 0:
+                ex_flop = 64.0 * mix["SQ_INSTS_VALU_FLOPS_FP32"]
+                out["roofline"]["executed"] = {
+                    "flop_per_launch": ex_flop, "tflops": ex_flop / (k0_ms * 1e-3) / 1e12,
+                    "frac": ex_flop / (k0_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                    "valu_instructions_per_launch": mix.get("SQ_INSTS_VALU"),
+                    "fp32_instructions_per_launch": sum(mix.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")),
+                    "source": "profiles/r3/" + profiled[0].replace("_pmc.csv", "_instmix.csv") + ": 64 x SQ_INSTS_VALU_FLOPS_FP32 per launch over this "
+                              "run's kernel time; FP32 lane-operations issued whether or not the lane was active"}
+            else:
+                out["roofline"]["executed"] = None
         if world == 1 and grouped:
             # the same frame through the flat sweep (north_star's every-ray-tests-every-sphere kernel)
             pf = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, sweep=capi.RT_SWEEP_FLAT, **part)

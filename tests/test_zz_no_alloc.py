@@ -78,3 +78,48 @@ def test_render_noalloc_matches_rt_render(capi):
     finally:
         ctx.close()
         ref_ctx.close()
+
+
+def test_render_noalloc_is_capturable(capi):
+    """What the entry point exists for: it can run where nothing may allocate or synchronise.  One call is recorded
+    under HIP stream capture (torch.cuda.graph on the stream the context renders on: a hipMalloc, hipFree, event
+    creation or stream synchronisation inside the capture fails it), nothing executes while recording, and the
+    replayed graph writes the frame rt_render gives, twice in a row."""
+    import torch
+    w, h, spp = 320, 180, 4
+    objs, cam = capi.make_scene(capi.RT_SCENE_GRID1K, w, h)
+    ref_ctx, ctx = capi.Context(0), capi.Context(0)
+    try:
+        for sweep in (capi.RT_SWEEP_FLAT, capi.RT_SWEEP_GROUPED):      # with and without the sample-split plane in the scratch array
+            p = capi.render_params(w, h, 5, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, sweep=sweep)
+            ref_ctx.upload_scene(objs, cam)
+            ref_ctx.render(p)
+            want_rgba, want_f32 = ref_ctx.download(capi.RT_FMT_RGBA8, w, h), ref_ctx.download(capi.RT_FMT_F32X4, w, h)
+            ctx.upload_scene(objs, cam)
+            stream = torch.cuda.Stream()
+            rgba = torch.zeros((w * h,), dtype=torch.int32, device="cuda")
+            f32 = torch.zeros((w * h * 4,), dtype=torch.float32, device="cuda")
+            ctx.set_stream(stream.cuda_stream)
+            try:
+                ctx.render_noalloc(p, rgba.data_ptr(), w * h * 4, f32.data_ptr(), w * h * 16)    # (first launch: code objects load outside the capture)
+                stream.synchronize()
+                rgba.zero_()
+                f32.zero_()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    ctx.render_noalloc(p, rgba.data_ptr(), w * h * 4, f32.data_ptr(), w * h * 16)
+                torch.cuda.synchronize()
+                assert int(rgba.abs().sum().item()) == 0                 # recorded, not run
+                for _ in range(2):
+                    rgba.zero_()
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    assert np.array_equal(rgba.cpu().numpy().view(np.uint8).reshape(h, w, 4), want_rgba), sweep
+                    assert np.array_equal(f32.cpu().numpy().reshape(h, w, 4).view(np.uint32), want_f32.view(np.uint32)), sweep
+                del graph
+            finally:
+                ctx.set_stream(0)
+    finally:
+        ctx.close()
+        ref_ctx.close()

@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../raytracer_amd/csrc"
 mkdir -p build_var/$name
-FLAGS="-O3 -fPIC -ffp-contract=off -I../../include -I. -Wall -Wno-unused-function --offload-arch=gfx950 -std=c++17 -mllvm -disable-promote-alloca-to-vector -mllvm -disable-promote-alloca-to-lds ${SCHED--mllvm -amdgpu-sched-strategy=max-memory-clause}"
+FLAGS="-O3 -fPIC -ffp-contract=off -I../../include -I. -Wall -Wno-unused-function --offload-arch=gfx950 -std=c++17 -mllvm -disable-promote-alloca-to-vector -mllvm -disable-promote-alloca-to-lds ${SCHED-}"
 pids=""
 /opt/rocm/bin/hipcc $FLAGS "$@" -c -o build_var/$name/rt_sweep_grouped.o rt_sweep_grouped.hip & pids="$pids $!"
 G3=build/rt_sweep_grouped3.o

@@ -15,6 +15,9 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
+META = {}
+
+
 def fold(root, sub, want):
     sums, launches = defaultdict(lambda: defaultdict(float)), defaultdict(set)
     for path in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
@@ -24,11 +27,15 @@ def fold(root, sub, want):
                 continue
             sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+            META[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
+                       r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
     return {k: {c: v / max(1, len(launches[(k, c)])) for c, v in cs.items()} for k, cs in sums.items()}
 
 
 def main(root):
     w = csv.writer(sys.stdout)
+    w.writerow(["# note: rocprofv3 reports vgpr = 64 for kernels whose code-object notes say 128 -- trust raytracer_amd/kernel_resources.json "
+                "(read from the notes); the scratch size is right, and is what bench.py matches a profile to a build by"])
     calib = {}
     for sub in ("calib_a", "calib_b"):
         for k, cs in fold(root, sub, "calib_").items():
@@ -47,6 +54,7 @@ def main(root):
     for k in sorted(mix):
         w.writerow([])
         w.writerow(["# " + k])
+        w.writerow(["# vgpr,agpr,sgpr,lds_block,scratch,grid,wg = " + ",".join(str(v) for v in META.get(k, ()))])
         w.writerow(["counter", "per_launch_summed_over_xcds"])
         for c in sorted(mix[k]):
             w.writerow([c, "%.0f" % mix[k][c]])

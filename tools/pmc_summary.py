@@ -15,6 +15,8 @@ def short(name):
 
 def main(root):
     w = csv.writer(sys.stdout)
+    w.writerow(["# note: rocprofv3 reports vgpr = 64 for kernels whose code-object notes say 128 -- trust raytracer_amd/kernel_resources.json "
+                "(read from the notes); the scratch size is right, and is what bench.py matches a profile to a build by"])
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
         w.writerow(["# kernel stats (rocprofv3 --kernel-trace --stats)"])
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct"])
