@@ -15,5 +15,5 @@ if [ "${GROUPED3:-0}" = 1 ]; then
   G3=build_var/$name/rt_sweep_grouped3.o
 fi
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librt_amd_$name.so build/rt_host.o build/rt_api.o build/rt_kernels_exact.o build/rt_sweep_small.o build_var/$name/rt_sweep_grouped.o $G3 build/rt_sweep_chunked.o build/rt_sweep_compact.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librt_amd_$name.so build/rt_host.o build/rt_api.o build/rt_kernels_exact.o build/rt_sweep_small.o build_var/$name/rt_sweep_grouped.o build/rt_sweep_grouped_fast.o $G3 build/rt_sweep_chunked.o build/rt_sweep_compact.o
 KERNEL_RESOURCES_JSON=1 ../../tools/kernel_resources.sh build_var/$name/rt_sweep_grouped.o | tr '}' '\n' | grep "Lb0ELi6ELb0ELi1E" | sed 's/.*"vgpr"/"vgpr"/' | sed "s/^/$name: /"
