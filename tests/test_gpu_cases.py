@@ -196,7 +196,12 @@ def test_prepass_band_plan(capi, gpu_ctx):
     gpu_ctx.render(capi.render_params(w, h, 5, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True))
     f32 = gpu_ctx.download(capi.RT_FMT_F32X4, w, h)
     rows = f32[..., 3].astype(np.float64).sum(axis=1)
-    for n, limit in ((2, 1.10), (4, 1.20), (8, 1.40)):      # a 1/16-resolution map of a thin, very expensive horizon
+    # Limits on the ESTIMATED work (the cost map's own unit), not on time: the map has one sample per 4x4 pixels, and the
+    # frame's most expensive rows -- the three or four under the horizon, 12x the average -- fall into one or two of its
+    # rows, so a cut next to them is off by up to a map row's worth of that cost: 1.4x at 8 bands of a 1080p frame.
+    # What the bands then take in TIME is measured per part by tools/band_balance.py (profiles/r3/band_balance.txt: 1.15x
+    # at 8 bands of the 4K frame, 1.05x for the strips, which need no map at all and are the default plan).
+    for n, limit in ((2, 1.10), (4, 1.20), (8, 1.40)):
         b = multigpu.plan_bands(cost, h, n)
         work = [rows[b[i]:b[i + 1]].sum() for i in range(n)]
         assert max(work) / (sum(work) / n) < limit, (n, work)
