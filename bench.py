@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", default="grid1k", choices=["default", "grid1k", "grid16k"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped"],
+    ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped", "sorted"],
                     help="flat: every ray tests every sphere; grouped: bounding-sphere groups of 8 are skipped when "
                          "missed; auto (the library default): grouped from 64 spheres up")
     ap.add_argument("--lanes", type=int, default=0,
@@ -232,7 +232,7 @@ def main():
 
     kind = {"default": capi.RT_SCENE_DEFAULT, "grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[args.scene]
     mode = capi.RT_MODE_EXACT if args.mode == "exact" else capi.RT_MODE_FAST
-    sweep = {"auto": capi.RT_SWEEP_AUTO, "flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED}[args.sweep]
+    sweep = {"auto": capi.RT_SWEEP_AUTO, "flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED, "sorted": capi.RT_SWEEP_SORTED}[args.sweep]
     W, H = args.width, args.height
     objs, cam = capi.make_scene(kind, W, H)
     ctx = capi.Context(local)

@@ -116,11 +116,19 @@ enum {
     RT_SWEEP_AUTO = 0,   /* grouped for scenes of 64 spheres or more, flat below                    */
     RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */
-    RT_SWEEP_GROUPED = 2 /* spheres are grouped at upload (8 per group along a Morton curve, 8
+    RT_SWEEP_GROUPED = 2,/* spheres are grouped at upload (8 per group along a Morton curve, 8
                             groups per super-group); a wave skips a group when all its rays pass
                             the group's bounding sphere at a distance.  Scenes of fewer than 64 spheres
                             take the flat sweep regardless                                         */
+    RT_SWEEP_SORTED = 3  /* the grouped sweep with TraceRay's bounce levels (main.cpp:103-109) run as
+                            separate launches: between two levels the hit points are sorted by where
+                            they lie, so that a wave's 64 rays start next to one another whatever the
+                            paths did before (large scenes of small reflective spheres, where paths
+                            scatter after one bounce).  Needs device memory per path -- 64 B x (max_depth
+                            + 1) + 100 B, held by the context -- and falls back to RT_SWEEP_GROUPED above
+                            RT_SORTED_MAX_BYTES; not with rt_render_noalloc or RT_OUT_COST              */
 };
+#define RT_SORTED_MAX_BYTES ((size_t)24 << 30)
 
 typedef struct rt_render_params {
     int32_t width;          /* pixel loop bounds (ImageWidth / ImageHeight, main.cpp:12-13)       */

@@ -19,7 +19,7 @@ RT_OBJ_SPHERE, RT_OBJ_TILED_PLANE = 0, 1
 RT_OUT_RGBA8, RT_OUT_F32X4, RT_OUT_COST = 1, 2, 4
 RT_FMT_RGB8, RT_FMT_RGBA8, RT_FMT_F32X4, RT_FMT_BMP_BODY = 0, 1, 2, 3
 RT_MODE_EXACT, RT_MODE_FAST = 0, 1
-RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED = 0, 1, 2
+RT_SWEEP_AUTO, RT_SWEEP_FLAT, RT_SWEEP_GROUPED, RT_SWEEP_SORTED = 0, 1, 2, 3
 RT_PLAN_AUTO, RT_PLAN_BANDS, RT_PLAN_STRIPS = 0, 1, 2
 RT_STRIP_COLS = 8
 RT_MAX_DEVICES = 8

@@ -44,6 +44,11 @@ struct rt_context {
     bool have_frame = false;
     int last_outputs = 0;
 
+    void *sorted_blob = nullptr;      // RT_SWEEP_SORTED: records | entry queues | permutation | cell counters | counts (one allocation)
+    size_t sorted_bytes = 0;
+    float cell_org[3] = {0, 0, 0}, cell_inv[3] = {0, 0, 0};   // the scene's grid of 2^RT_SORTED_CELL_BITS cells (set by rt_upload_scene)
+    float far_bound_sorted = INFINITY;   // RtSceneDev::far_bound as RT_SWEEP_SORTED uses it
+    int32_t cell_bits[3] = {RT_SORTED_CELL_BITS / 3, RT_SORTED_CELL_BITS / 3, RT_SORTED_CELL_BITS / 3};
     void *sample_buf = nullptr;       // sample split: one float4 per (sample, pixel)
     size_t sample_bytes = 0;
     int sample_split = 1;
@@ -367,6 +372,7 @@ void rt_destroy(rt_context *ctx)
     if (ctx->region_dev) (void)hipFree(ctx->region_dev);
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
+    if (ctx->sorted_blob) (void)hipFree(ctx->sorted_blob);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -887,6 +893,29 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         }
         double diag2 = 0.0;
         for (int a = 0; a < 3; a++) diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        // RT_SWEEP_SORTED: 64 cells per axis over the box around the spheres (hit points outside it -- planes -- clamp to its faces)
+        double cell_scale = 1.0;
+        if (const char *v = debug_env("RT_AMD_CELL_SCALE")) cell_scale = atof(v);
+        {
+            double ext[3];
+            bool ok = !geom.empty();
+            for (int a = 0; a < 3; a++) { ext[a] = (hi[a] - lo[a]) * cell_scale; ok = ok && ext[a] == ext[a] && ext[a] < 1e30; if (!(ext[a] > 1e-3)) ext[a] = 1e-3; }
+            // the bits of a cell's number between the axes: the next bit goes to the axis whose cells are the longest
+            int bits[3] = {0, 0, 0};
+            for (int k = 0; k < RT_SORTED_CELL_BITS; k++) {
+                int best = 0;
+                for (int a = 1; a < 3; a++) if (ext[a] / (double)(1 << bits[a]) > ext[best] / (double)(1 << bits[best])) best = a;
+                bits[best]++;
+            }
+            if (const char *v = debug_env("RT_AMD_CELL_BITS")) sscanf(v, "%d,%d,%d", &bits[0], &bits[1], &bits[2]);
+            if (bits[0] < 0 || bits[1] < 0 || bits[2] < 0 || bits[0] + bits[1] + bits[2] != RT_SORTED_CELL_BITS) { bits[0] = bits[1] = bits[2] = RT_SORTED_CELL_BITS / 3; }
+            for (int a = 0; a < 3; a++) {
+                const double mid = 0.5 * (hi[a] + lo[a]);
+                ctx->cell_bits[a] = bits[a];
+                ctx->cell_org[a] = ok ? (float)(mid - 0.5 * ext[a]) : 0.0f;
+                ctx->cell_inv[a] = ok ? (float)((double)(1 << bits[a]) / ext[a]) : 0.0f;
+            }
+        }
         // (measured, headline / 16k scene at 4K: 0.25 6.00 / 24.0 ms, 0.5 5.88 / 24.9, 1 6.14 / 25.0, off 7.05 / 25.5; the 16k scene at
         // 1080p: 0.25 7.7 ms, 0.5 13.2 -- a wave that keeps a half-far lane walks most of the scene with all its lanes, which
         // takes the longer the larger the scene is, and at lower resolutions that one wave is the frame)
@@ -895,6 +924,10 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         const double reach = fraction * 0.5 * std::sqrt(diag2);        // of the radius of the box around the spheres
         const double fb = reach * reach / 5.0;                          // allowance^2 = 5 * (2^-19 |pos|^2) = 5 * filter bound
         ctx->scene_grouped.far_bound = (fraction > 0.0 && fb == fb && fb < 1e30 && !geom.empty()) ? (float)fb : INFINITY;
+        // RT_SWEEP_SORTED gives every far segment a wave of its own, so a lane on the way to far no longer holds up 63 others
+        // and the threshold can sit lower (measured on the 16k scene, 4K / 1080p: half the fraction 17.4 / 6.9 ms, the same
+        // fraction 17.8 / 8.6, a quarter 21.2 / 7.9)
+        ctx->far_bound_sorted = ctx->scene_grouped.far_bound * 0.25f;
     }
     for (int a = 0; a < 3; a++) ctx->scene_grouped.sigma[a] = grp.sigma[a];
     for (int a = 0; a < 3; a++) ctx->scene_grouped.metric[a] = grp.sigma[a] * grp.sigma[a];
@@ -974,6 +1007,39 @@ static int ensure_plane(rt_context *ctx, int plane, size_t bytes)
         ctx->own_bytes[plane] = bytes;
     }
     ctx->cur_plane[plane] = ctx->own_plane[plane];
+    return RT_OK;
+}
+
+// RT_SWEEP_SORTED's buffers for a frame of `paths` paths and `levels` bounce levels (rt_sweep_sorted.hip): what they take ...
+static size_t sorted_bytes_needed(size_t paths, int levels)
+{
+    const size_t cells = rt_sorted_cells();
+    return paths * 64 * (size_t)levels + 3 * paths * 48 + paths * 4 + cells * 4 * (size_t)levels + 256;
+}
+// ... and the buffers themselves, grown when a render needs more (kept between renders)
+static int ensure_sorted(rt_context *ctx, size_t paths, int levels, RtSortedDev *out)
+{
+    const size_t need = sorted_bytes_needed(paths, levels);
+    if (ctx->sorted_bytes < need) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->sorted_blob) RT_HIP(ctx, hipFree(ctx->sorted_blob));
+        ctx->sorted_blob = nullptr;
+        ctx->sorted_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->sorted_blob, need));
+        ctx->sorted_bytes = need;
+    }
+    unsigned char *b = (unsigned char *)ctx->sorted_blob;
+    const size_t cells = rt_sorted_cells();
+    out->rec = (float4 *)b; b += paths * 64 * (size_t)levels;
+    out->queue[0] = (float4 *)b; b += paths * 48;
+    out->queue[1] = (float4 *)b; b += paths * 48;
+    out->farq = (float4 *)b; b += paths * 48;
+    out->perm = (unsigned *)b; b += paths * 4;
+    out->hist = (unsigned *)b; b += cells * 4 * (size_t)levels;
+    out->count = (unsigned *)b;
+    out->count_far = out->count + (RT_MAX_LEVELS + 1);
+    out->cap = (unsigned)paths;
+    for (int a = 0; a < 3; a++) { out->cell_org[a] = ctx->cell_org[a]; out->cell_inv[a] = ctx->cell_inv[a]; out->cell_bits[a] = ctx->cell_bits[a]; }
     return RT_OK;
 }
 
@@ -1231,7 +1297,7 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     const int out_width = strips ? rt_interleaved_count(p->width, p->col_interleave, p->col_phase) : p->width;
     if (p->mode != RT_MODE_EXACT && p->mode != RT_MODE_FAST)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown mode %d", p->mode);
-    if (p->sweep != RT_SWEEP_AUTO && p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED)
+    if (p->sweep != RT_SWEEP_AUTO && p->sweep != RT_SWEEP_FLAT && p->sweep != RT_SWEEP_GROUPED && p->sweep != RT_SWEEP_SORTED)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: unknown sweep %d", p->sweep);
     int outputs = p->outputs ? p->outputs : RT_OUT_RGBA8;
     if (outputs & ~(RT_OUT_RGBA8 | RT_OUT_F32X4 | RT_OUT_COST))
@@ -1298,6 +1364,15 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
         fr.chunk = n_pairs < cap ? n_pairs : cap;
     }
 
+    // RT_SWEEP_SORTED: the bounce levels as separate launches (rt_sweep_sorted.hip); what it cannot do goes the one-launch way
+    bool sorted = false;
+    RtSortedDev sorted_dev = {};
+    if (grouped && p->sweep == RT_SWEEP_SORTED) {
+        if (na) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: RT_SWEEP_SORTED keeps per-path buffers that the context allocates");
+        if (outputs & RT_OUT_COST) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: RT_OUT_COST needs a one-launch sweep (RT_SWEEP_GROUPED)");
+        const size_t paths = px * (size_t)p->spp;
+        sorted = paths > 0 && paths < ((size_t)1 << 31) && sorted_bytes_needed(paths, p->max_depth + 1) <= RT_SORTED_MAX_BYTES;
+    }
     // One sample per lane where the kernel allows it (see the kernel's comment) ...
     fr.tile_w = fr.tile_h = 8;
     const RtSceneDev &use_scene = grouped ? ctx->scene_grouped : ctx->scene;
@@ -1314,8 +1389,12 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     // traffic (32 B per sample and pixel) on scenes whose sweeps are long (rt_sweep_can_split_samples);
     // capped at 1 GiB.
     const size_t split_bytes = px * (size_t)p->spp * sizeof(float4);
-    const bool want_split = ctx->sample_split && !fr.lane_samples && !ctx->simple_kernel && px > 0 &&
+    const bool want_split = ctx->sample_split && !fr.lane_samples && !ctx->simple_kernel && px > 0 && !sorted &&
                             rt_sweep_can_split_samples(use_scene, fr, grouped);
+    if (sorted) {
+        int rc = ensure_sorted(ctx, px * (size_t)p->spp, p->max_depth + 1, &sorted_dev);
+        if (rc) return rc;
+    }
     if (na) {
         // the sample-split plane lives in this device's scratch array behind the counters; a render whose
         // plane does not fit is rejected (the allocating path would grow its buffer instead)
@@ -1381,6 +1460,11 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
         // RT_MODE_FAST: same sweeps, shading by throughput accumulation (no per-segment records).
         // The straight-transcription kernel has only the exact formulation.
         if (ctx->simple_kernel) RT_HIP(ctx, rt_launch_trace_exact(ctx->scene, ctx->cam, fr, smp, sdev, ctx->stream));
+        else if (sorted) {
+            RtSceneDev sc = ctx->scene_grouped;
+            sc.far_bound = ctx->far_bound_sorted;
+            RT_HIP(ctx, rt_launch_trace_sorted(sc, ctx->cam, fr, smp, sdev, p->mode == RT_MODE_FAST, sorted_dev, ctx->stream));
+        }
         else RT_HIP(ctx, rt_launch_trace_sweep(grouped ? ctx->scene_grouped : ctx->scene, ctx->cam, fr, smp, sdev,
                                                p->mode == RT_MODE_FAST, grouped, ctx->stream));
         if (fr.sample_buf) RT_HIP(ctx, rt_launch_resolve_samples(fr, ctx->stream));

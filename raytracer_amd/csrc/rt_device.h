@@ -40,6 +40,7 @@
 #define RT_GROUP_PAIRS 4      // pair records per group (8 spheres)
 #define RT_SUPER_GROUPS 8      // groups per super-group (64 spheres)
 #define RT_N_REGIONS 16
+#define RT_SORTED_CELL_BITS 15 // RT_SWEEP_SORTED: the scene is cut into 2^15 cells (measured: 2^18 no better, and its counters take 100 us to scan per level)
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
@@ -129,6 +130,23 @@ struct RtSamples {
     float xy[2 * RT_MAX_SPP];
     float lens[2 * RT_MAX_SPP];   // lens-plane offsets (along right, along up) when RtFrameDev::lens_on
 };
+
+// RT_SWEEP_SORTED (rt_sweep_sorted.hip): the buffers one render's bounce levels pass through
+struct RtSortedDev {
+    float4 *rec;          // records of the path segments, 4 float4 each, level-major: (level * cap + index) * 4
+    float4 *queue[2];     // entries queued for a level, 3 float4 each; queue[level & 1] feeds `level`
+    unsigned *perm;       // sorted position -> entry of the level being swept
+    unsigned *hist;       // [level][cell]: entries per cell, then (scan) where the cell's entries start
+    float4 *farq;         // entries of the level being swept whose hit point is a far one (one wave each, see the kernels)
+    unsigned *count;      // [level]: entries queued
+    unsigned *count_far;  // [level]: of them, far ones (count + RT_MAX_LEVELS + 1)
+    unsigned cap;         // paths of the frame = records per level at most
+    float cell_org[3], cell_inv[3];   // cell of a point p along axis a: (p[a] - cell_org[a]) * cell_inv[a], clamped to [0, 2^cell_bits[a])
+    int32_t cell_bits[3];             // RT_SORTED_CELL_BITS shared between the axes so that cells come out roughly cubic
+};
+size_t rt_sorted_cells(void);
+hipError_t rt_launch_trace_sorted(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame, const RtSamples &samples,
+                                  RtStatsDev *stats, bool fast, const RtSortedDev &sorted, hipStream_t stream);
 
 // kernel launchers
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,
