@@ -278,6 +278,7 @@ def main():
     my_flop = (st["sphere_tests_run"] + st["group_tests_run"]) * FLOP_PER_SPHERE_TEST + my_rays * n_pl * FLOP_PER_PLANE_TEST
     brute_flop = my_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
     grouped = st["group_tests_run"] > 0
+    sorted_levels = st.get("sweep") == capi.RT_SWEEP_SORTED      # RT_SWEEP_AUTO resolved (rt_stats.sweep)
 
     params = capi.render_params(W, H, args.depth, args.spp, offsets=offsets, mode=mode, sweep=sweep, **part)
 
@@ -380,7 +381,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.scene}: {len(objs)} objects ({n_sph} spheres, {st['n_emitters']} emissive), "
-                                   f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}, sweep {args.sweep}",
+                                   f"{W}x{H}, MAX_DEPTH {args.depth}, {args.spp} spp, mode {args.mode}, sweep {args.sweep}" + (" (sorted)" if sorted_levels and args.sweep == "auto" else ""),
                        "rays_per_frame": int(rays), "bands": bounds,
                        "rank0_ray_classes": {k: int(st[k]) for k in ("primary_rays", "reflection_rays", "shadow_rays", "hits", "lit",
                                                                          "sphere_tests", "sphere_tests_run", "group_tests_run", "exact_tests_run")},
@@ -396,7 +397,9 @@ def main():
                                           "valu_busy_profiled is",
                          "kernel_ms": k0_ms,
                          "algorithmic_flop_per_launch": int(my_flop),
-                         "kernel": "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)",
+                         "kernel": ("sorted_level_kernel x levels + far segments + sorted_shade_kernel (sorted sweep: one launch per bounce level; "
+                                    "kernel_ms spans them all)" if sorted_levels else
+                                    "trace_sweep_kernel (" + ("grouped" if grouped else "flat") + " sweep)"),
                          "brute_force_equivalent_tflops": (brute_flop / (k0_ms * 1e-3)) / 1e12 if k0_ms > 0 else 0.0,
                          # the framebuffer is the only HBM traffic the algorithm asks for: 4 B per pixel per launch
                          "hbm_write_gbps": (band.numel() * 4 / (k0_ms * 1e-3)) / 1e9 if k0_ms > 0 else 0.0,
@@ -412,6 +415,8 @@ def main():
             ("grid1k", 3840, 2160, 5, 4, "exact", False): ("headline_pmc.csv", "trace_sweep_kernel<false, true, false, 6, false, 0>", "rt_sweep_compact", "ILb0ELb1ELb0ELi6ELb0ELi0E"),
             ("grid16k", 3840, 2160, 5, 1, "exact", True): ("grid16k_pmc.csv", "trace_sweep_kernel<false, false, false, 6, false, 2>", "rt_sweep_grouped3", "ILb0ELb0ELb0ELi6ELb0ELi2E"),
         }.get((args.scene, W, H, args.depth, args.spp, args.mode, bool(grouped)))
+        if sorted_levels:
+            profiled = None      # (the committed PMC summaries are of the one-launch kernels)
         if world == 1 and profiled:
             # not measurable from inside this process (PMC counters need rocprofv3 around it): taken from the
             # committed rocprofv3 summary of this same command, and only while the kernel is the one profiled

@@ -113,7 +113,9 @@ enum {
 
 /* How a ray visits the sphere list.  Every choice gives the same image, bit for bit. */
 enum {
-    RT_SWEEP_AUTO = 0,   /* grouped for scenes of 64 spheres or more, flat below                    */
+    RT_SWEEP_AUTO = 0,   /* flat below 64 spheres, grouped from there on; sorted for scenes of more than
+                            4096 spheres when the render has 2^18 paths or more, its buffers fit and
+                            nothing rules it out (rt_render_noalloc, RT_OUT_COST)                   */
     RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */
     RT_SWEEP_GROUPED = 2,/* spheres are grouped at upload (8 per group along a Morton curve, 8
@@ -215,6 +217,8 @@ typedef struct rt_stats {
     double gather_ms;           /* the slowest of those copies                                       */
     uint32_t replans;           /* RT_PLAN_BANDS: cost pre-passes this context has run so far (each one blocks)   */
     int32_t device_plan;        /* RT_PLAN_BANDS or RT_PLAN_STRIPS: what the last frame used                     */
+    int32_t sweep;              /* RT_SWEEP_FLAT, _GROUPED or _SORTED: what the last render took (RT_SWEEP_AUTO resolved) */
+    int32_t reserved;
 } rt_stats;
 
 typedef struct rt_context rt_context;

@@ -66,7 +66,7 @@ class Stats(C.Structure):
                 ("n_devices", C.c_uint32), ("device_id", C.c_int32 * RT_MAX_DEVICES), ("device_row_begin", C.c_int32 * RT_MAX_DEVICES),
                 ("device_row_end", C.c_int32 * RT_MAX_DEVICES), ("device_kernel_ms", C.c_double * RT_MAX_DEVICES),
                 ("device_gather_ms", C.c_double * RT_MAX_DEVICES), ("gather_ms", C.c_double),
-                ("replans", C.c_uint32), ("device_plan", C.c_int32)]
+                ("replans", C.c_uint32), ("device_plan", C.c_int32), ("sweep", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXPORTS = [

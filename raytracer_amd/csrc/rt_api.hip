@@ -1039,6 +1039,10 @@ static int ensure_sorted(rt_context *ctx, size_t paths, int levels, RtSortedDev 
     out->count = (unsigned *)b;
     out->count_far = out->count + (RT_MAX_LEVELS + 1);
     out->cap = (unsigned)paths;
+    // (measured on the 16k-sphere scene, levels sorted by themselves up to 1 / 2 / 3 / 5 of MAX_DEPTH 5: 4K 20.7 / 18.5 / 17.6 / 17.4 ms,
+    // 1080p 6.55 / 6.26 / 6.25 / 6.41 ms: deep levels of a small frame hold too few segments to be worth a launch of their own)
+    out->final_level = paths >= ((size_t)1 << 22) ? RT_MAX_LEVELS : 3;
+    if (const char *v = debug_env("RT_AMD_SORTED_FINAL")) out->final_level = atoi(v);
     for (int a = 0; a < 3; a++) { out->cell_org[a] = ctx->cell_org[a]; out->cell_inv[a] = ctx->cell_inv[a]; out->cell_bits[a] = ctx->cell_bits[a]; }
     return RT_OK;
 }
@@ -1370,8 +1374,16 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     if (grouped && p->sweep == RT_SWEEP_SORTED) {
         if (na) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: RT_SWEEP_SORTED keeps per-path buffers that the context allocates");
         if (outputs & RT_OUT_COST) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render: RT_OUT_COST needs a one-launch sweep (RT_SWEEP_GROUPED)");
+    }
+    {
+        // RT_SWEEP_AUTO takes it where it was measured to win: scenes large enough for the three-level bounds (paths scatter
+        // over thousands of spheres after one bounce) at a quarter of a million paths or more (16k-sphere scene: 4K frame 20.1 ->
+        // 17.4 ms, an eighth of it in strips 8.3 -> 4.6 ms, 1080p 6.4 -> 6.3 ms; the 1028-sphere scene loses: 4.7 -> 8.2 ms)
         const size_t paths = px * (size_t)p->spp;
-        sorted = paths > 0 && paths < ((size_t)1 << 31) && sorted_bytes_needed(paths, p->max_depth + 1) <= RT_SORTED_MAX_BYTES;
+        const bool fits = paths > 0 && paths < ((size_t)1 << 31) && sorted_bytes_needed(paths, p->max_depth + 1) <= RT_SORTED_MAX_BYTES;
+        const bool wanted = p->sweep == RT_SWEEP_SORTED ||
+                            (p->sweep == RT_SWEEP_AUTO && !na && !(outputs & RT_OUT_COST) && ctx->scene_grouped.n_supers > 64 && paths >= ((size_t)1 << 18));
+        sorted = grouped && wanted && fits;
     }
     // One sample per lane where the kernel allows it (see the kernel's comment) ...
     fr.tile_w = fr.tile_h = 8;
@@ -1483,6 +1495,7 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
     ctx->stats.primary_rays = (uint64_t)px * (uint64_t)p->spp;
     ctx->stats.n_objects = (uint64_t)ctx->scene.n_objects;
     ctx->stats.n_emitters = (uint64_t)ctx->scene.n_emit;
+    ctx->stats.sweep = sorted ? RT_SWEEP_SORTED : grouped ? RT_SWEEP_GROUPED : RT_SWEEP_FLAT;
     return RT_OK;
 }
 
@@ -1647,6 +1660,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out)
             total.exact_tests_run += st.exact_tests_run;
             total.n_objects = st.n_objects;
             total.n_emitters = st.n_emitters;
+            total.sweep = st.sweep;
             total.device_kernel_ms[i] = st.kernel_ms;
             total.kernel_ms = std::max(total.kernel_ms, st.kernel_ms);
             total.kernel_ms_total = std::max(total.kernel_ms_total, st.kernel_ms_total);

@@ -141,6 +141,7 @@ struct RtSortedDev {
     unsigned *count;      // [level]: entries queued
     unsigned *count_far;  // [level]: of them, far ones (count + RT_MAX_LEVELS + 1)
     unsigned cap;         // paths of the frame = records per level at most
+    int32_t final_level;  // the last level that is sorted and launched by itself: its waves follow their paths to the end
     float cell_org[3], cell_inv[3];   // cell of a point p along axis a: (p[a] - cell_org[a]) * cell_inv[a], clamped to [0, 2^cell_bits[a])
     int32_t cell_bits[3];             // RT_SORTED_CELL_BITS shared between the axes so that cells come out roughly cubic
 };

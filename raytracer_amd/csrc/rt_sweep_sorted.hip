@@ -120,8 +120,12 @@ __device__ __forceinline__ void flush_stats(bool counted, unsigned n_refl, unsig
 // FAR: the far kernel's call (one segment per wave); otherwise a segment whose hit point lies so far out that its rays have
 // to be tested against every sphere (RtSceneDev::far_bound, dense_sweep) is not swept here but handed to that kernel.
 template <bool STATS, int GROUPED, bool FAR>
+// hand_over: far segments go to the far queue (else they are swept here, one at a time, as in the one-launch kernel).
+// keep: the segment the reflection ray found is not queued but returned (next, next_rec, next_alive): the caller follows
+// the path itself (the levels from RtSortedDev::final_level on).
 __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Segment &seg, unsigned rec, int level,
-                                               unsigned &n_refl, unsigned &n_shadow, unsigned &n_hits, SweepCount &cnt)
+                                               unsigned &n_refl, unsigned &n_shadow, unsigned &n_hits, SweepCount &cnt,
+                                               bool hand_over, bool keep, Segment &next_seg, unsigned &next_rec, bool &next_alive)
 {
     const int lane = threadIdx.x & 63;
     V3 pos = v3(0, 0, 0), refl = v3(0, 0, 0), n = v3(0, 0, 0);
@@ -131,7 +135,7 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
     SceneArg &sc = ad->sc;
     const int n_emit = sc.n_emit;
     if (alive) pos = seg.o + seg.d * seg.dist;                               // main.cpp:94
-    if constexpr (!FAR) {
+    if (!FAR && hand_over) {
         // A wave whose 64 lanes are far runs 64 passes over the scene one after the other (the tail of every launch);
         // queued, each such segment gets a wave of its own in the launch that follows this one.
         const bool is_far = alive && filter_bound(pos) >= sc.far_bound;
@@ -207,10 +211,10 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
     }
     // (the hit points of a wave fall into a handful of cells: one atomic per distinct cell, not 64 on the same counter)
     const V3 o = pos + refl * 0.001f;                                        // main.cpp:108
-    const unsigned cell = push ? cell_of(so, o + refl * next.dist) : 0u;
+    const unsigned cell = (push && !keep) ? cell_of(so, o + refl * next.dist) : 0u;
     unsigned rank = 0;
     {
-        unsigned long long todo = pm;
+        unsigned long long todo = keep ? 0ull : pm;
         while (todo) {
             const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cell, __builtin_ctzll(todo));
             const unsigned long long same = __ballot(push && cell == c) & todo;
@@ -227,14 +231,38 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
         if (push) {
             const unsigned u = base + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
             child = (int)u;
-            float4 *const e4 = so.queue[(level + 1) & 1] + (size_t)u * 3;
-            e4[0] = make_float4(o.x, o.y, o.z, next.dist);
-            e4[1] = make_float4(refl.x, refl.y, refl.z, __int_as_float(next.slot));
-            e4[2] = make_float4(__int_as_float(next.id), __uint_as_float(cell), __uint_as_float(rank), 0.0f);
+            if (keep) {
+                next_seg.o = o; next_seg.d = refl; next_seg.dist = next.dist; next_seg.slot = next.slot; next_seg.id = next.id;
+                next_rec = min(u, so.cap - 1u);
+            } else {
+                float4 *const e4 = so.queue[(level + 1) & 1] + (size_t)u * 3;
+                e4[0] = make_float4(o.x, o.y, o.z, next.dist);
+                e4[1] = make_float4(refl.x, refl.y, refl.z, __int_as_float(next.slot));
+                e4[2] = make_float4(__int_as_float(next.id), __uint_as_float(cell), __uint_as_float(rank), 0.0f);
+            }
         }
         r4[1].w = __int_as_float(child);
         r4[3] = make_float4(__uint_as_float((unsigned)lit), __uint_as_float((unsigned)(lit >> 32)), __uint_as_float((unsigned)alt),
                             __uint_as_float((unsigned)(alt >> 32)));
+    }
+    next_alive = keep && push;
+}
+
+// A lane's segment, and -- from the final level on -- the segments its reflection rays find, to the end of the path.
+template <bool STATS, int GROUPED, bool FAR>
+__device__ __forceinline__ void sorted_path(float4 *lds, bool alive, Segment seg, unsigned rec, int level,
+                                            unsigned &n_refl, unsigned &n_shadow, unsigned &n_hits, SweepCount &cnt)
+{
+    const int final_level = fresh_sorted()->so.final_level, max_depth = fresh_args()->fr.max_depth;
+    for (int lvl = level;; lvl++) {
+        const bool keep = level >= final_level && lvl < max_depth;
+        Segment nseg;
+        nseg.o = v3(0, 0, 0); nseg.d = v3(0, 0, 0); nseg.dist = 0.0f; nseg.slot = INT_MIN; nseg.id = -1;
+        unsigned nrec = 0;
+        bool nalive = false;
+        sorted_segment<STATS, GROUPED, FAR>(lds, alive, seg, rec, lvl, n_refl, n_shadow, n_hits, cnt, lvl == level, keep, nseg, nrec, nalive);
+        if (!keep || !__any(nalive)) break;
+        seg = nseg; rec = nrec; alive = nalive;
     }
 }
 
@@ -318,7 +346,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
             const unsigned path = pixel * spp + (unsigned)s;
             if (in_image && !alive)                                          // main.cpp:90-93: the shading pass returns (0.1, 0.1, 0.1)
                 fresh_sorted()->so.rec[(size_t)path * 4] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kNoHit));
-            sorted_segment<STATS, GROUPED, false>(lds, alive, seg, path, 0, n_refl, n_shadow, n_hits, cnt);
+            sorted_path<STATS, GROUPED, false>(lds, alive, seg, path, 0, n_refl, n_shadow, n_hits, cnt);
         }
         flush_stats<STATS>(in_image, n_refl, n_shadow, n_hits, 0u, cnt);
     } else if constexpr (FAR) {
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
                 seg.id = __float_as_int(e2.x);
                 rec = min(__float_as_uint(e2.y), so.cap - 1u);
             }
-            sorted_segment<STATS, GROUPED, true>(lds, alive, seg, rec, level, n_refl, n_shadow, n_hits, cnt);
+            sorted_path<STATS, GROUPED, true>(lds, alive, seg, rec, level, n_refl, n_shadow, n_hits, cnt);
         }
         flush_stats<STATS>(true, n_refl, n_shadow, n_hits, 0u, cnt);
     } else {
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
                 seg.d = v3(e1.x, e1.y, e1.z); seg.slot = __float_as_int(e1.w);
                 seg.id = __float_as_int(e2.x);
             }
-            sorted_segment<STATS, GROUPED, false>(lds, alive, seg, u, level, n_refl, n_shadow, n_hits, cnt);
+            sorted_path<STATS, GROUPED, false>(lds, alive, seg, u, level, n_refl, n_shadow, n_hits, cnt);
         }
         flush_stats<STATS>(true, n_refl, n_shadow, n_hits, 0u, cnt);
     }
@@ -515,7 +543,9 @@ hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStr
     hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, true>), dim3((unsigned)tiles), dim3(64), kGroupedLdsBytes, stream, args);
     if (with_far) hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, false, true>), dim3(kFarWaves), dim3(64), kGroupedLdsBytes, stream, args);
     const unsigned waves = (unsigned)std::min<unsigned long long>((paths + 63) / 64, 16384), perm_blocks = (unsigned)std::min<unsigned long long>((paths + 255) / 256, 4096);
-    for (int level = 1; level < levels; level++) {
+    // (levels past the final one are followed by the final level's waves themselves)
+    if (args.so.final_level < 1) args.so.final_level = 1;
+    for (int level = 1; level < levels && level <= args.so.final_level; level++) {
         args.level = level;
         hipLaunchKernelGGL(sorted_scan_kernel, dim3(1), dim3(1024), 0, stream, args.so.hist + (size_t)level * kCells);
         hipLaunchKernelGGL(sorted_perm_kernel, dim3(perm_blocks), dim3(256), 0, stream, args.so, level);

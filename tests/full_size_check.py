@@ -29,7 +29,7 @@ def main():
     ctx = capi.Context(0)
     ctx.upload_scene(objs, cam)
     gpu = {}
-    for name, sweep in (("flat", capi.RT_SWEEP_FLAT), ("grouped", capi.RT_SWEEP_GROUPED)):
+    for name, sweep in (("flat", capi.RT_SWEEP_FLAT), ("grouped", capi.RT_SWEEP_GROUPED), ("sorted", capi.RT_SWEEP_SORTED)):
         ctx.render(capi.render_params(w, h, depth, spp, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4, sweep=sweep))
         gpu[name] = (ctx.download(capi.RT_FMT_RGB8, w, h), ctx.download(capi.RT_FMT_F32X4, w, h), ctx.stats()["kernel_ms"])
         print(f"gpu {name}: {gpu[name][2]:.2f} ms", flush=True)

@@ -132,13 +132,13 @@ def main():
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--scenes", str(args.scenes), "--seed", str(args.seed),
                                "--child", path], env=env)
         simple = open(path).read().split()
-    res = render_all(capi, ctx, args.seed, args.scenes, [capi.RT_SWEEP_FLAT, capi.RT_SWEEP_GROUPED], args.cpu)
+    res = render_all(capi, ctx, args.seed, args.scenes, [capi.RT_SWEEP_FLAT, capi.RT_SWEEP_GROUPED, capi.RT_SWEEP_SORTED], args.cpu)
     bad = 0
     for i, (n, w, h, depth, spp, frames) in enumerate(res):
         ok = all(f == simple[i] for f in frames)
         bad += not ok
         print(f"scene {i}: {n} objects {w}x{h} depth {depth} spp {spp}: {'ok' if ok else 'MISMATCH ' + str([frames[0][:8], frames[1][:8], simple[i][:8]])}", flush=True)
-    print(f"{len(res) - bad}/{len(res)} scenes identical across flat, grouped and transcription kernels"
+    print(f"{len(res) - bad}/{len(res)} scenes identical across flat, grouped, sorted and transcription kernels"
           + (" and the CPU checker" if args.cpu else ""))
     return 1 if bad else 0
 

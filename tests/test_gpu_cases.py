@@ -70,12 +70,12 @@ def test_config3_default_4k_16spp_band(capi, oracle, gpu_ctx):
     assert_parity(rgb_o[rows[0]:rows[1]], f32_o[rows[0]:rows[1]], rgb_g[rows[0]:rows[1]], f32_g[rows[0]:rows[1]])
 
 
-@pytest.mark.parametrize("sweep", ["flat", "grouped"])
+@pytest.mark.parametrize("sweep", ["flat", "grouped", "sorted"])
 def test_full_size_sparse_pixels(capi, gpu_ctx, sweep):
     """Full-resolution frames of the synthetic configs (grid-1024 at 4K depth 5 and 8K depth 8, grid-16k at
     4K depth 5) against sparse-pixel radiance from the reference's own TraceRay (tests/golden/scenes.json,
     made by tests/gen_golden.py from oracle/_ref/libref_trace_d5/d8.so), through both sweeps."""
-    sweep = {"flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED}[sweep]
+    sweep = {"flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED, "sorted": capi.RT_SWEEP_SORTED}[sweep]
     scenes = json.load(open(os.path.join(GOLD, "scenes.json")))["scenes"]
     for name, s in scenes.items():
         objs, cam = capi.make_scene(s["kind"], s["w"], s["h"], frame=s["frame"])
@@ -399,6 +399,72 @@ def test_grouped_sweep_is_bit_identical(capi, gpu_ctx, scene, size, depth, spp):
         flat = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, mode=mode, sweep=capi.RT_SWEEP_FLAT)
         grouped = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, mode=mode, sweep=capi.RT_SWEEP_GROUPED)
         assert _same_frame(flat, grouped), (scene, size, mode)
+
+
+@pytest.mark.parametrize("scene,size,depth,spp", [("grid16k", (640, 360), 5, 1), ("grid16k", (203, 117), 3, 4), ("grid1k", (480, 270), 8, 4),
+                                                  ("grid1k", (333, 211), 5, 1), ("grid1k", (320, 200), 0, 1), ("grid16k", (800, 450), 15, 1)])
+def test_sorted_sweep_is_bit_identical(capi, gpu_ctx, scene, size, depth, spp):
+    """RT_SWEEP_SORTED runs TraceRay's bounce levels as separate launches and deals each level's hit points to waves in
+    the order of the cells they lie in (far ones to waves of their own); which rays share a wave must not show: the frame
+    (radiance bits, per-pixel ray counts, 8-bit image) and the ray census are the flat sweep's, in both modes, with the
+    deep levels sorted by themselves or followed by the last sorted level's waves."""
+    w, h = size
+    kind = {"grid1k": capi.RT_SCENE_GRID1K, "grid16k": capi.RT_SCENE_GRID16K}[scene]
+    objs, cam = capi.make_scene(kind, w, h)
+    keys = ("reflection_rays", "shadow_rays", "hits", "lit", "primary_rays")
+    for mode in (capi.RT_MODE_EXACT, capi.RT_MODE_FAST):
+        flat = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, mode=mode, sweep=capi.RT_SWEEP_FLAT, stats=True)
+        census = {k: gpu_ctx.stats()[k] for k in keys}
+        srt = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, mode=mode, sweep=capi.RT_SWEEP_SORTED, stats=True)
+        assert _same_frame(flat, srt), (scene, size, mode)
+        assert {k: gpu_ctx.stats()[k] for k in keys} == census
+        assert gpu_ctx.stats()["group_tests_run"] > 0                      # (it did go through the grouped layout)
+
+
+def test_sorted_sweep_options(capi, oracle, gpu_ctx, monkeypatch):
+    """The sorted sweep under the options a render can carry: row bands and column strips reproduce the full frame,
+    the thin lens and the running mean match the one-launch sweep, every far-lane threshold gives the same bits, the
+    16k-sphere frame agrees with the CPU oracle, and what it cannot do is refused by name."""
+    w, h = 640, 360
+    objs, cam = capi.make_scene(capi.RT_SCENE_GRID16K, w, h)
+    full = render_gpu(capi, gpu_ctx, objs, cam, w, h, 5, 1, sweep=capi.RT_SWEEP_SORTED)
+    p = capi.render_params(w, h, 5, 1, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4)
+    rgb_o, f32_o, _ = oracle.render(objs, cam, p, threads=16)
+    assert np.array_equal(full[0], rgb_o) and np.array_equal(full[1].view(np.uint32), f32_o.view(np.uint32))
+    bounds = [0, 1, 97, 200, 360]
+    parts = [render_gpu(capi, gpu_ctx, objs, cam, w, h, 5, 1, rows=(bounds[i], bounds[i + 1]), sweep=capi.RT_SWEEP_SORTED) for i in range(4)]
+    assert np.array_equal(np.concatenate([q[1] for q in parts]).view(np.uint32), full[1].view(np.uint32))
+    from raytracer_amd import multigpu
+    both = capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4
+    for n in (2, 3):
+        got = np.zeros_like(full[1])
+        for phase in range(n):
+            cols = multigpu.interleaved_col_index(w, n, phase)
+            gpu_ctx.render(capi.render_params(w, h, 5, 1, sweep=capi.RT_SWEEP_SORTED, outputs=both, interleave=(n, phase), first_row=h // 2))
+            got[:, cols] = gpu_ctx.download(capi.RT_FMT_F32X4, len(cols), h)
+        assert np.array_equal(got.view(np.uint32), full[1].view(np.uint32)), n
+    # thin lens + running mean (ray generation and write-out only)
+    rng = np.random.RandomState(5)
+    lens = ((rng.rand(4, 2) - 0.5) * 0.2).astype(np.float32)
+    frames = {}
+    for sweep in (capi.RT_SWEEP_GROUPED, capi.RT_SWEEP_SORTED):
+        for k in range(3):
+            gpu_ctx.render(capi.render_params(w, h, 3, 4, sweep=sweep, outputs=both, lens=lens, focal_length=30.0, accumulate=k))
+        frames[sweep] = (gpu_ctx.download(capi.RT_FMT_RGB8, w, h), gpu_ctx.download(capi.RT_FMT_F32X4, w, h))
+    assert _same_frame(frames[capi.RT_SWEEP_GROUPED], frames[capi.RT_SWEEP_SORTED])
+    # far segments: all of them, a mix, none
+    monkeypatch.setenv("RT_AMD_DEBUG", "1")
+    for fraction in ("1e-9", "0.02", "0"):
+        monkeypatch.setenv("RT_AMD_FAR_FRACTION", fraction)
+        for final in ("1", "2", "15"):
+            monkeypatch.setenv("RT_AMD_SORTED_FINAL", final)
+            got = render_gpu(capi, gpu_ctx, objs, cam, w, h, 5, 1, sweep=capi.RT_SWEEP_SORTED)
+            assert _same_frame(full, got), (fraction, final)
+    monkeypatch.delenv("RT_AMD_FAR_FRACTION")
+    monkeypatch.delenv("RT_AMD_SORTED_FINAL")
+    gpu_ctx.upload_scene(objs, cam)
+    with pytest.raises(capi.RtError, match="RT_OUT_COST"):
+        gpu_ctx.render(capi.render_params(w, h, 5, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True, sweep=capi.RT_SWEEP_SORTED))
 
 
 @pytest.mark.parametrize("fraction", ["1e-9", "0.02", "0"])

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--sweep", default="auto", choices=["auto", "flat", "grouped", "sorted"])
     args = ap.parse_args()
     import torch  # noqa: F401
     from raytracer_amd import capi, multigpu
@@ -31,8 +32,10 @@ def main():
     cost = multigpu.prepass_row_cost(ctx, objs, cam, W, H, args.depth)
     hot = multigpu.hot_row(cost)
     print(f"hot row {hot}")
+    sweep = {"auto": capi.RT_SWEEP_AUTO, "flat": capi.RT_SWEEP_FLAT, "grouped": capi.RT_SWEEP_GROUPED, "sorted": capi.RT_SWEEP_SORTED}[args.sweep]
+
     def timed(**kw):
-        p = capi.render_params(W, H, args.depth, args.spp, **kw)
+        p = capi.render_params(W, H, args.depth, args.spp, sweep=sweep, **kw)
         ctx.render(p)
         ctx.render(p)
         return ctx.stats()["kernel_ms"]
