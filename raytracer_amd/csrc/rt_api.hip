@@ -908,7 +908,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
                 bits[best]++;
             }
             if (const char *v = debug_env("RT_AMD_CELL_BITS")) sscanf(v, "%d,%d,%d", &bits[0], &bits[1], &bits[2]);
-            if (bits[0] < 0 || bits[1] < 0 || bits[2] < 0 || bits[0] + bits[1] + bits[2] != RT_SORTED_CELL_BITS) { bits[0] = bits[1] = bits[2] = RT_SORTED_CELL_BITS / 3; }
+            if (bits[0] < 0 || bits[1] < 0 || bits[2] < 0 || bits[0] + bits[1] + bits[2] != RT_SORTED_CELL_BITS) { bits[0] = bits[1] = bits[2] = (RT_SORTED_CELL_BITS) / 3; }
             for (int a = 0; a < 3; a++) {
                 const double mid = 0.5 * (hi[a] + lo[a]);
                 ctx->cell_bits[a] = bits[a];

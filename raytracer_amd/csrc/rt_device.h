@@ -40,7 +40,9 @@
 #define RT_GROUP_PAIRS 4      // pair records per group (8 spheres)
 #define RT_SUPER_GROUPS 8      // groups per super-group (64 spheres)
 #define RT_N_REGIONS 16
+#ifndef RT_SORTED_CELL_BITS
 #define RT_SORTED_CELL_BITS 15 // RT_SWEEP_SORTED: the scene is cut into 2^15 cells (measured: 2^18 no better, and its counters take 100 us to scan per level)
+#endif
 #define RT_QUEUE_BYTES (7 * 256 * 4)   // LDS request queue of the sweep kernel: 7 fields x 256 threads
 
 struct RtPlaneDev {
