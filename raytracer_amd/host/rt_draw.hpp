@@ -29,7 +29,7 @@ struct DrawSceneOptions {
     std::vector<int> devices;   // more than one entry: the frame is shared between these HIP devices (rt_create_multi),
                                 // the counterpart of the reference's thread fan-out inside DrawScene (main.cpp:193-227)
     int mode = RT_MODE_EXACT;   // RT_MODE_FAST: radiance to rounding instead of bit-identical
-    int sweep = RT_SWEEP_AUTO;  // RT_SWEEP_FLAT / RT_SWEEP_GROUPED: same image either way
+    int sweep = RT_SWEEP_AUTO;  // RT_SWEEP_FLAT / RT_SWEEP_GROUPED / RT_SWEEP_SORTED: same image every way
     double *kernelMs = nullptr; // optional: device time of the trace kernel (summed over frames)
     // raytracer_win's progressive mode (raytracer_win/main.cpp:280-327, camera.h:147-173): `frames`
     // single-sample frames folded into a running mean, each with its own sub-pixel jitter and, when

@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     parser.set_optional<float>("l", "lens", 0.0f, "thin-lens radius (depth of field), e.g. 0.14; needs --focus");
     parser.set_optional<float>("F", "focus", 0.0f, "distance from the camera to the focal point");
     parser.set_optional<int>("m", "mode", 0, "0 = bit-identical to the reference, 1 = fast (radiance to rounding)");
-    parser.set_optional<int>("w", "sweep", 0, "0 = auto, 1 = flat (every ray tests every sphere), 2 = grouped");
+    parser.set_optional<int>("w", "sweep", 0, "0 = auto, 1 = flat (every ray tests every sphere), 2 = grouped, 3 = sorted (grouped, one launch per bounce level)");
     if (!parser.run()) return 2;
 
     const int partitions = parser.get<int>("p");

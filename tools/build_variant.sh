@@ -21,5 +21,5 @@ if [ "${FAST:-0}" = 1 ]; then
   GF=build_var/$name/rt_sweep_grouped_fast.o
 fi
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librt_amd_$name.so build/rt_host.o build/rt_api.o build/rt_kernels_exact.o build/rt_sweep_small.o build_var/$name/rt_sweep_grouped.o $GF $G3 build/rt_sweep_chunked.o build/rt_sweep_compact.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../librt_amd_$name.so build/rt_host.o build/rt_api.o build/rt_kernels_exact.o build/rt_sweep_small.o build_var/$name/rt_sweep_grouped.o $GF $G3 build/rt_sweep_chunked.o build/rt_sweep_compact.o build/rt_sweep_sorted.o
 KERNEL_RESOURCES_JSON=1 ../../tools/kernel_resources.sh build_var/$name/rt_sweep_grouped.o | tr '}' '\n' | grep "Lb0ELi6ELb0ELi1E" | sed 's/.*"vgpr"/"vgpr"/' | sed "s/^/$name: /"

@@ -28,7 +28,7 @@ def main(root):
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             k = short(r["Kernel_Name"])
-            if "trace_" not in k:
+            if "trace_" not in k and "sorted_" not in k:
                 continue
             sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
@@ -38,10 +38,10 @@ def main(root):
         w.writerow([])
         w.writerow(["# " + k])
         w.writerow(["# vgpr,agpr,sgpr,lds_block,scratch,grid,wg = " + ",".join(str(v) for v in meta[k])])
-        w.writerow(["counter", "per_launch_summed_over_xcds", "launches"])
+        w.writerow(["counter", "per_launch_summed_over_xcds", "launches", "all_launches"])
         for c in sorted(sums[k]):
             n = len(launches[(k, c)])
-            w.writerow([c, "%.0f" % (sums[k][c] / max(1, n)), n])
+            w.writerow([c, "%.0f" % (sums[k][c] / max(1, n)), n, "%.0f" % sums[k][c]])
 
 
 if __name__ == "__main__":
