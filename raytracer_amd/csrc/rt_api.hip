@@ -44,6 +44,8 @@ struct rt_context {
     bool have_frame = false;
     int last_outputs = 0;
 
+    hipStream_t side_stream = nullptr;   // RT_SWEEP_SORTED: level 0's far segments run beside the sorted levels
+    hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
     void *sorted_blob = nullptr;      // RT_SWEEP_SORTED: records | entry queues | permutation | cell counters | counts (one allocation)
     size_t sorted_bytes = 0;
     float cell_org[3] = {0, 0, 0}, cell_inv[3] = {0, 0, 0};   // the scene's grid of 2^RT_SORTED_CELL_BITS cells (set by rt_upload_scene)
@@ -373,6 +375,9 @@ void rt_destroy(rt_context *ctx)
     if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
     if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
     if (ctx->sorted_blob) (void)hipFree(ctx->sorted_blob);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_level0) (void)hipEventDestroy(ctx->ev_level0);
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1014,12 +1019,21 @@ static int ensure_plane(rt_context *ctx, int plane, size_t bytes)
 static size_t sorted_bytes_needed(size_t paths, int levels)
 {
     const size_t cells = rt_sorted_cells();
-    return paths * 64 * (size_t)levels + 3 * paths * 48 + paths * 4 + cells * 4 * (size_t)levels + 256;
+    return paths * 64 * (size_t)levels + 4 * paths * 48 + paths * 4 + cells * 4 * (size_t)levels + 256;
 }
 // ... and the buffers themselves, grown when a render needs more (kept between renders)
 static int ensure_sorted(rt_context *ctx, size_t paths, int levels, RtSortedDev *out)
 {
     const size_t need = sorted_bytes_needed(paths, levels);
+    if (!ctx->side_stream) {
+        int lo = 0, hi = 0;
+        RT_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));     // (lo: the numerically greatest = least urgent)
+        int prio = lo;
+        if (const char *v = debug_env("RT_AMD_SIDE_PRIORITY")) prio = atoi(v) ? lo : 0;
+        RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio));
+    }
+    if (!ctx->ev_level0) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_level0, hipEventDisableTiming));
+    if (!ctx->ev_side) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
     if (ctx->sorted_bytes < need) {
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->sorted_blob) RT_HIP(ctx, hipFree(ctx->sorted_blob));
@@ -1034,15 +1048,19 @@ static int ensure_sorted(rt_context *ctx, size_t paths, int levels, RtSortedDev 
     out->queue[0] = (float4 *)b; b += paths * 48;
     out->queue[1] = (float4 *)b; b += paths * 48;
     out->farq = (float4 *)b; b += paths * 48;
+    out->farq0 = (float4 *)b; b += paths * 48;
     out->perm = (unsigned *)b; b += paths * 4;
     out->hist = (unsigned *)b; b += cells * 4 * (size_t)levels;
     out->count = (unsigned *)b;
     out->count_far = out->count + (RT_MAX_LEVELS + 1);
+    out->count_kept = out->count + 2 * (RT_MAX_LEVELS + 1);
     out->cap = (unsigned)paths;
     // (measured on the 16k-sphere scene, levels sorted by themselves up to 1 / 2 / 3 / 5 of MAX_DEPTH 5: 4K 20.7 / 18.5 / 17.6 / 17.4 ms,
     // 1080p 6.55 / 6.26 / 6.25 / 6.41 ms: deep levels of a small frame hold too few segments to be worth a launch of their own)
     out->final_level = paths >= ((size_t)1 << 22) ? RT_MAX_LEVELS : 3;
     if (const char *v = debug_env("RT_AMD_SORTED_FINAL")) out->final_level = atoi(v);
+    out->far0_waves = 0;
+    if (const char *v = debug_env("RT_AMD_SORTED_FAR0_WAVES")) out->far0_waves = atoi(v);
     for (int a = 0; a < 3; a++) { out->cell_org[a] = ctx->cell_org[a]; out->cell_inv[a] = ctx->cell_inv[a]; out->cell_bits[a] = ctx->cell_bits[a]; }
     return RT_OK;
 }
@@ -1475,7 +1493,8 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
         else if (sorted) {
             RtSceneDev sc = ctx->scene_grouped;
             sc.far_bound = ctx->far_bound_sorted;
-            RT_HIP(ctx, rt_launch_trace_sorted(sc, ctx->cam, fr, smp, sdev, p->mode == RT_MODE_FAST, sorted_dev, ctx->stream));
+            RT_HIP(ctx, rt_launch_trace_sorted(sc, ctx->cam, fr, smp, sdev, p->mode == RT_MODE_FAST, sorted_dev, ctx->stream, ctx->side_stream,
+                                               ctx->ev_level0, ctx->ev_side));
         }
         else RT_HIP(ctx, rt_launch_trace_sweep(grouped ? ctx->scene_grouped : ctx->scene, ctx->cam, fr, smp, sdev,
                                                p->mode == RT_MODE_FAST, grouped, ctx->stream));

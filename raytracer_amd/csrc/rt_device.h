@@ -139,17 +139,21 @@ struct RtSortedDev {
     float4 *queue[2];     // entries queued for a level, 3 float4 each; queue[level & 1] feeds `level`
     unsigned *perm;       // sorted position -> entry of the level being swept
     unsigned *hist;       // [level][cell]: entries per cell, then (scan) where the cell's entries start
-    float4 *farq;         // entries of the level being swept whose hit point is a far one (one wave each, see the kernels)
+    float4 *farq;         // entries of the level being swept whose hit point is a far one (one wave each, see the kernels) ...
+    float4 *farq0;        // ... level 0's apart: they are swept on a stream of their own while the levels go on
     unsigned *count;      // [level]: entries queued
     unsigned *count_far;  // [level]: of them, far ones (count + RT_MAX_LEVELS + 1)
+    unsigned *count_kept; // [level]: segments followed by the wave that found them (records from the top of the level's)
     unsigned cap;         // paths of the frame = records per level at most
+    int32_t far0_waves;   // waves of level 0's far launch (it shares the chip with the sorted levels)
     int32_t final_level;  // the last level that is sorted and launched by itself: its waves follow their paths to the end
     float cell_org[3], cell_inv[3];   // cell of a point p along axis a: (p[a] - cell_org[a]) * cell_inv[a], clamped to [0, 2^cell_bits[a])
     int32_t cell_bits[3];             // RT_SORTED_CELL_BITS shared between the axes so that cells come out roughly cubic
 };
 size_t rt_sorted_cells(void);
 hipError_t rt_launch_trace_sorted(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame, const RtSamples &samples,
-                                  RtStatsDev *stats, bool fast, const RtSortedDev &sorted, hipStream_t stream);
+                                  RtStatsDev *stats, bool fast, const RtSortedDev &sorted, hipStream_t stream, hipStream_t side,
+                                  hipEvent_t ev_level0, hipEvent_t ev_side);
 
 // kernel launchers
 hipError_t rt_launch_trace_sweep(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame,

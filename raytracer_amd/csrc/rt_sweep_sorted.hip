@@ -147,7 +147,7 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
             fbase = (unsigned)__builtin_amdgcn_readlane((int)fbase, __builtin_ctzll(fm));
             if (is_far) {
                 const unsigned f = min(fbase + (unsigned)__builtin_popcountll(fm & ((1ull << lane) - 1ull)), so.cap - 1u);
-                float4 *const e4 = so.farq + (size_t)f * 3;
+                float4 *const e4 = (level == 0 ? so.farq0 : so.farq) + (size_t)f * 3;
                 e4[0] = make_float4(seg.o.x, seg.o.y, seg.o.z, seg.dist);
                 e4[1] = make_float4(seg.d.x, seg.d.y, seg.d.z, __int_as_float(seg.slot));
                 e4[2] = make_float4(__int_as_float(seg.id), __uint_as_float(rec), 0.0f, 0.0f);
@@ -206,9 +206,11 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
     // queue the next level's entries: one atomic per wave for the slots, one per lane on its cell's counter
     SortedArg &so = fresh_sorted()->so;
     const unsigned long long pm = __ballot(push);
+    // (a kept segment's record comes from the TOP of the next level's records, a queued one's -- which is also its entry's slot --
+    // from the bottom: the two never meet, a level has at most `cap` segments, and the queue holds nothing but entries)
     unsigned base = 0;
     if (pm) {
-        if (lane == __builtin_ctzll(pm)) base = atomicAdd(&so.count[level + 1], (unsigned)__builtin_popcountll(pm));
+        if (lane == __builtin_ctzll(pm)) base = atomicAdd(keep ? &so.count_kept[level + 1] : &so.count[level + 1], (unsigned)__builtin_popcountll(pm));
         base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(pm));
     }
     // (the hit points of a wave fall into a handful of cells: one atomic per distinct cell, not 64 on the same counter)
@@ -232,7 +234,8 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
         float4 *const r4 = so.rec + ((size_t)level * so.cap + rec) * 4;
         int child = want_refl ? kRayMissed : kNoRay;
         if (push) {
-            const unsigned u = base + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+            const unsigned nth = base + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+            const unsigned u = keep ? so.cap - 1u - min(nth, so.cap - 1u) : nth;
             child = (int)u;
             if (keep) {
                 next_seg.o = o; next_seg.d = refl; next_seg.dist = next.dist; next_seg.slot = next.slot; next_seg.id = next.id;
@@ -258,7 +261,9 @@ __device__ __forceinline__ void sorted_path(float4 *lds, bool alive, Segment seg
 {
     const int final_level = fresh_sorted()->so.final_level, max_depth = fresh_args()->fr.max_depth;
     for (int lvl = level;; lvl++) {
-        const bool keep = level >= final_level && lvl < max_depth;
+        // (level 0's far segments -- most of a frame's -- run beside the sorted levels on a stream of their own, so what their
+        // reflection rays find cannot join level 1's queue: their waves follow it themselves)
+        const bool keep = ((FAR && level == 0) || level >= final_level) && lvl < max_depth;
         Segment nseg;
         nseg.o = v3(0, 0, 0); nseg.d = v3(0, 0, 0); nseg.dist = 0.0f; nseg.slot = INT_MIN; nseg.id = -1;
         unsigned nrec = 0;
@@ -356,14 +361,23 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
         SortedArgsPtr sa = fresh_sorted();
         const int level = sa->level;
         const unsigned count = min(sa->so.count_far[level], sa->so.cap);
-        for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
+        // Level 0's far segments are taken from a counter, not by stride: the launch beside the sorted levels is a thin one (it
+        // shares the chip with them), and a second one behind the last level takes whatever the first has not got to by then.
+        unsigned *const next_far0 = sa->so.count_kept + (RT_MAX_LEVELS + 1);
+        auto take = [&](unsigned prev) -> unsigned {
+            if (level != 0) return prev == 0xffffffffu ? blockIdx.x : prev + gridDim.x;
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(next_far0, 1u);
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        };
+        for (unsigned i = take(0xffffffffu); i < count; i = take(i)) {
             const bool alive = lane == 0;
             Segment seg;
             seg.o = v3(0, 0, 0); seg.d = v3(0, 0, 0); seg.dist = 0.0f; seg.slot = INT_MIN; seg.id = -1;
             unsigned rec = 0;
             if (alive) {
                 SortedArg &so = fresh_sorted()->so;
-                const float4 *const e4 = so.farq + (size_t)i * 3;
+                const float4 *const e4 = (level == 0 ? so.farq0 : so.farq) + (size_t)i * 3;
                 const float4 e0 = e4[0], e1 = e4[1], e2 = e4[2];
                 seg.o = v3(e0.x, e0.y, e0.z); seg.dist = e0.w;
                 seg.d = v3(e1.x, e1.y, e1.z); seg.slot = __float_as_int(e1.w);
@@ -522,8 +536,11 @@ __global__ __launch_bounds__(256) void sorted_shade_kernel(RtSortedKernArgs by_v
     }
 }
 
+// `side`: a second stream for level 0's far segments, which depend on level 0's launch alone and on which only the shading
+// pass depends (ev_level0: recorded on `stream` behind level 0; ev_side: recorded on `side` behind the far launch).
 template <bool STATS, int GROUPED>
-hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStream_t stream)
+hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStream_t stream, hipStream_t side, hipEvent_t ev_level0,
+                                hipEvent_t ev_side)
 {
     RtSortedKernArgs args = proto;
     const RtFrameDev &fr = args.base.fr;
@@ -534,7 +551,7 @@ hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStr
     if (tiles > 0x7fffffffll || paths > 0x7fffffffull || paths > args.so.cap) return hipErrorInvalidValue;
     const int levels = fr.max_depth + 1;
     // the counters of this frame: entries queued per level, entries per cell and level
-    hipError_t e = hipMemsetAsync(args.so.count, 0, sizeof(unsigned) * 2 * (RT_MAX_LEVELS + 1), stream);    // count | count_far
+    hipError_t e = hipMemsetAsync(args.so.count, 0, sizeof(unsigned) * (3 * (RT_MAX_LEVELS + 1) + 1), stream);    // count | count_far | count_kept | next far segment of level 0
     if (e != hipSuccess) return e;
     if (levels > 1) {
         e = hipMemsetAsync(args.so.hist + kCells, 0, sizeof(unsigned) * (size_t)kCells * (size_t)(levels - 1), stream);
@@ -544,7 +561,13 @@ hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStr
     constexpr unsigned kFarWaves = 8192;            // (twice what the chip holds at 4 waves per SIMD)
     const bool with_far = args.base.sc.far_bound < INFINITY;
     hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, true>), dim3((unsigned)tiles), dim3(64), kGroupedLdsBytes, stream, args);
-    if (with_far) hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, false, true>), dim3(kFarWaves), dim3(64), kGroupedLdsBytes, stream, args);
+    if (with_far) {
+        if ((e = hipEventRecord(ev_level0, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side, ev_level0, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, false, true>), dim3(args.so.far0_waves > 0 ? (unsigned)args.so.far0_waves : 1024u), dim3(64),
+                           kGroupedLdsBytes, side, args);
+        if ((e = hipEventRecord(ev_side, side)) != hipSuccess) return e;
+    }
     const unsigned waves = (unsigned)std::min<unsigned long long>((paths + 63) / 64, 16384), perm_blocks = (unsigned)std::min<unsigned long long>((paths + 255) / 256, 4096);
     // (levels past the final one are followed by the final level's waves themselves)
     if (args.so.final_level < 1) args.so.final_level = 1;
@@ -557,6 +580,11 @@ hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStr
     }
     const unsigned n_px = (unsigned)((unsigned long long)fr.width * (unsigned long long)rows);
     args.level = 0;
+    if (with_far) {
+        // the levels are through: whatever is left of level 0's far segments gets the whole chip
+        hipLaunchKernelGGL((sorted_level_kernel<STATS, GROUPED, false, true>), dim3(kFarWaves), dim3(64), kGroupedLdsBytes, stream, args);
+        if ((e = hipStreamWaitEvent(stream, ev_side, 0)) != hipSuccess) return e;
+    }
     if (fast) hipLaunchKernelGGL((sorted_shade_kernel<STATS, true>), dim3((n_px + 255) / 256), dim3(256), 0, stream, args);
     else hipLaunchKernelGGL((sorted_shade_kernel<STATS, false>), dim3((n_px + 255) / 256), dim3(256), 0, stream, args);
     return hipGetLastError();
@@ -567,13 +595,14 @@ hipError_t launch_sorted_levels(const RtSortedKernArgs &proto, bool fast, hipStr
 size_t rt_sorted_cells(void) { return kCells; }
 
 hipError_t rt_launch_trace_sorted(const RtSceneDev &scene, const rt_camera &cam, const RtFrameDev &frame, const RtSamples &samples,
-                                  RtStatsDev *stats, bool fast, const RtSortedDev &sorted, hipStream_t stream)
+                                  RtStatsDev *stats, bool fast, const RtSortedDev &sorted, hipStream_t stream, hipStream_t side,
+                                  hipEvent_t ev_level0, hipEvent_t ev_side)
 {
     RtSortedKernArgs args;
     args.base.sc = scene; args.base.cam = cam; args.base.fr = frame; args.base.smp = samples; args.base.stats = stats;
     args.so = sorted;
     args.level = 0;
     const bool three = scene.n_supers > 64;        // (the ray-by-ray bound tests start one level up, as in rt_launch_trace_sweep)
-    if (stats) return three ? launch_sorted_levels<true, 2>(args, fast, stream) : launch_sorted_levels<true, 1>(args, fast, stream);
-    return three ? launch_sorted_levels<false, 2>(args, fast, stream) : launch_sorted_levels<false, 1>(args, fast, stream);
+    if (stats) return three ? launch_sorted_levels<true, 2>(args, fast, stream, side, ev_level0, ev_side) : launch_sorted_levels<true, 1>(args, fast, stream, side, ev_level0, ev_side);
+    return three ? launch_sorted_levels<false, 2>(args, fast, stream, side, ev_level0, ev_side) : launch_sorted_levels<false, 1>(args, fast, stream, side, ev_level0, ev_side);
 }
