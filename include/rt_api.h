@@ -127,7 +127,7 @@ enum {
                             they lie, so that a wave's 64 rays start next to one another whatever the
                             paths did before (large scenes of small reflective spheres, where paths
                             scatter after one bounce).  Needs device memory per path -- 64 B x (max_depth
-                            + 1) + 100 B, held by the context -- and falls back to RT_SWEEP_GROUPED above
+                            + 1) + 196 B, held by the context -- and falls back to RT_SWEEP_GROUPED above
                             RT_SORTED_MAX_BYTES; not with rt_render_noalloc or RT_OUT_COST              */
 };
 #define RT_SORTED_MAX_BYTES ((size_t)24 << 30)

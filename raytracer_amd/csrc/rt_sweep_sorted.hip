@@ -7,22 +7,27 @@
 // 16k-sphere scene 70 % of the kernel's wave-cycles were such sweeps.  None of that is inherent: a ray's result does not
 // depend on which lanes it shares a wave with (filter and bound tests are conservative, the exact test is the
 // reference's arithmetic), so the segments of one level may be dealt to waves in any order.  Here they are dealt in
-// order of the cell of a 64^3 grid over the scene (Morton order) their hit point lies in: a wave's 64 hit points then
+// order of the cell of a 2^15-cell grid over the scene (Morton order) their hit point lies in: a wave's 64 hit points then
 // sit next to one another, every lane has work, the shadow rays towards an emitter form a beam again, and the bounds a
 // wave visits are those of one neighbourhood.
 //
-// The pipeline, all on one stream, nothing read back by the host:
-//   level 0   sorted_level_kernel<.., 0>: primary rays, tile by tile as in the one-launch kernel (camera rays are
-//             coherent as they come), the hit point, the K rays that leave it; writes the segment's RECORD (what the
+// The pipeline, nothing read back by the host:
+//   level 0   sorted_level_kernel<.., LEVEL0>: primary rays, tile by tile as in the one-launch kernel (camera rays are
+//             coherent as they come), the hit point, the rays that leave it; writes the segment's RECORD (what the
 //             shading pass needs: pos, normal, reflected direction, material, lit masks) and, when the reflection ray
 //             hit something, queues an ENTRY for level 1 (the ray and what it hit) with the cell of its hit point and
-//             its rank among that cell's entries (one atomic on the cell's counter)
+//             its rank among that cell's entries (one atomic per wave and distinct cell on the cell's counter)
 //   per level l = 1 .. max_depth:
 //       sorted_scan_kernel    cell counters -> start of each cell's range (exclusive prefix sum, one workgroup)
 //       sorted_perm_kernel    entry u goes to position start[cell] + rank: perm[position] = u
 //       sorted_level_kernel   lane s takes entry perm[s]: hit point, record, sweeps, queue for level l + 1
-//     (launched for the worst case -- one lane per path -- and bounded by the device-side count: waves past it leave
-//     at once; nothing waits for the host)
+//     (a fixed number of waves that stride over the sorted entries, bounded by the device-side count; nothing waits for
+//     the host)
+//   far segments (hit points so far out that every sphere is a candidate: dense_sweep) are not swept where they turn up
+//             but queued, and sorted_level_kernel<.., FAR> gives each a wave of its own: level l's right behind level l's
+//             launch; level 0's -- most of a frame's -- on a second stream beside the sorted levels, with a second launch
+//             behind the last level for what is left (they take segments from a counter, and follow what their
+//             reflection rays find themselves instead of queueing it)
 //   sorted_shade_kernel       one thread per pixel: walks each sample's chain of records down, then shades it
 //             deepest-first in the reference's operation order (main.cpp:109-186) -- or top-down with the throughput
 //             accumulator (RT_MODE_FAST) -- adds the samples in order (main.cpp:203-210) and writes the pixel
@@ -31,8 +36,8 @@
 // bit (tests/test_gpu_cases.py::test_sorted_sweep_is_bit_identical).
 //
 // Memory (device, held by the context between renders of the same size): 64 B per record x paths x (max_depth + 1)
-// levels, two entry buffers of 48 B x paths, 4 B x paths of permutation, 1 MB of cell counters per level; a 4K frame at
-// 1 spp and MAX_DEPTH 5 takes 4.1 GB.  rt_render falls back to RT_SWEEP_GROUPED above RT_SORTED_MAX_BYTES.
+// levels, four entry buffers of 48 B x paths, 4 B x paths of permutation, 128 KB of cell counters per level; a 4K frame at
+// 1 spp and MAX_DEPTH 5 takes 4.8 GB.  rt_render falls back to RT_SWEEP_GROUPED above RT_SORTED_MAX_BYTES.
 #include "rt_sweep_kernel.inc"
 
 #ifndef RT_SORTED_SHADOW_K
