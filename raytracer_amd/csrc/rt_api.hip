@@ -1028,9 +1028,8 @@ static int ensure_sorted(rt_context *ctx, size_t paths, int levels, RtSortedDev 
     if (!ctx->side_stream) {
         int lo = 0, hi = 0;
         RT_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));     // (lo: the numerically greatest = least urgent)
-        int prio = lo;
-        if (const char *v = debug_env("RT_AMD_SIDE_PRIORITY")) prio = atoi(v) ? lo : 0;
-        RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio));
+        // (the least urgent priority there is: it is filler work.  Measured: no different from the default priority.)
+        RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
     }
     if (!ctx->ev_level0) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_level0, hipEventDisableTiming));
     if (!ctx->ev_side) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));

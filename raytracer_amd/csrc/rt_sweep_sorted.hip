@@ -40,16 +40,6 @@
 // 1 spp and MAX_DEPTH 5 takes 4.8 GB.  rt_render falls back to RT_SWEEP_GROUPED above RT_SORTED_MAX_BYTES.
 #include "rt_sweep_kernel.inc"
 
-#ifndef RT_SORTED_SHADOW_K
-#define RT_SORTED_SHADOW_K kMaxK      // shadow rays swept together in the sorted levels
-#endif
-#ifndef RT_SORTED_SHADOW_FROM
-#define RT_SORTED_SHADOW_FROM 1
-#endif
-#ifndef RT_SORTED_SPLIT_REFL
-#define RT_SORTED_SPLIT_REFL 1
-#endif
-
 namespace {
 
 constexpr int kCellBitsTotal = RT_SORTED_CELL_BITS;        // shared between the axes (rt_api.hip: rt_upload_scene)
@@ -193,16 +183,15 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
         int e0 = 0;
         if (!__any(alive)) e0 = n_emit;
         else if (any_refl) {
-            // (RT_SORTED_SPLIT_REFL: the reflection rays of a wave fan out -- off small spheres even those of a tile's primary
-            // hits -- while its shadow rays form beams, so the reflection ray is swept by itself and does not cost the shadow
-            // classes their beam test; 16k-sphere scene at 4K: sorted levels only 18.6 -> 17.4 ms, level 0 as well -> 16.4 ms,
-            // bound tests 2.8e10 -> 1.5e10 -> 0.8e10)
-            const int ne = RT_SORTED_SPLIT_REFL ? 0 : min(n_emit, kMaxK - 1);
-            trace_group_k<true, false, GROUPED>(1 + ne, sc, lds, 0, alive, pos, refl, want_refl, 0, lit, alt, next, next_hit, cnt);
-            e0 = ne;
+            // The reflection ray is swept by itself, not with the first shadow rays as in the one-launch kernel: the reflection rays
+            // of a wave fan out -- off small spheres even those of a tile's primary hits -- while its shadow rays form beams, and
+            // together the fan costs the shadow classes their beam test (16k-sphere scene at 4K: sorted levels only 18.6 -> 17.4 ms,
+            // level 0 as well -> 16.4 ms, bound tests 2.8e10 -> 1.5e10 -> 0.8e10).  The shadow rays then go kMaxK at a time (one
+            // or two per sweep: 28.8 / 23.6 vs 21.3 ms at the time; 4 + 4 instead of 5 + 3 for eight emitters: the same).
+            trace_group_k<true, false, GROUPED>(1, sc, lds, 0, alive, pos, refl, want_refl, 0, lit, alt, next, next_hit, cnt);
         }
         while (e0 < n_emit) {
-            const int ne = min(n_emit - e0, (level >= RT_SORTED_SHADOW_FROM) ? RT_SORTED_SHADOW_K : kMaxK);
+            const int ne = min(n_emit - e0, kMaxK);
             trace_group_k<false, false, GROUPED>(ne, sc, lds, 0, alive, pos, refl, false, e0, lit, alt, next, next_hit, cnt);
             e0 += ne;
         }
