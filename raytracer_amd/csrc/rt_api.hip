@@ -1422,7 +1422,13 @@ static int render_impl(rt_context *ctx, const rt_render_params *p, const NoAlloc
                             rt_sweep_can_split_samples(use_scene, fr, grouped);
     if (sorted) {
         int rc = ensure_sorted(ctx, px * (size_t)p->spp, p->max_depth + 1, &sorted_dev);
-        if (rc) return rc;
+        if (rc && p->sweep == RT_SWEEP_AUTO && !ctx->sorted_blob) {
+            // no room for the buffers (a GPU shared with others): AUTO was a preference, the one-launch sweep needs none
+            (void)hipGetLastError();
+            sorted = false;
+        } else if (rc) {
+            return rc;
+        }
     }
     if (na) {
         // the sample-split plane lives in this device's scratch array behind the counters; a render whose
