@@ -38,6 +38,9 @@
 // Memory (device, held by the context between renders of the same size): 64 B per record x paths x (max_depth + 1)
 // levels, four entry buffers of 48 B x paths, 4 B x paths of permutation, 128 KB of cell counters per level; a 4K frame at
 // 1 spp and MAX_DEPTH 5 takes 4.8 GB.  rt_render falls back to RT_SWEEP_GROUPED above RT_SORTED_MAX_BYTES.
+#ifndef RT_DISTANCE_CULL
+#define RT_DISTANCE_CULL 3      // a reflection ray swept on its own stops asking for bounds behind its hit, nearest bounds first (sweep_near_first())
+#endif
 #include "rt_sweep_kernel.inc"
 
 namespace {
