@@ -41,6 +41,9 @@
 #ifndef RT_DISTANCE_CULL
 #define RT_DISTANCE_CULL 3      // a reflection ray swept on its own stops asking for bounds behind its hit, nearest bounds first (sweep_near_first())
 #endif
+#ifndef RT_DENSE_PRUNE
+#define RT_DENSE_PRUNE 1
+#endif
 #include "rt_sweep_kernel.inc"
 
 namespace {
