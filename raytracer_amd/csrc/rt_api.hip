@@ -402,6 +402,7 @@ struct GroupedScene {
     int n_tail_pairs = 0;                  // records after the groups' that every sweep tests (the emissive spheres, when few)
     float sigma[3] = {1.0f, 1.0f, 1.0f};   // the metric the bounds are measured in: |x|_S = |diag(sigma) x|, min sigma = 1
     float kappa = 1.0f;                    // max sigma
+    float box_lo[3] = {-INFINITY, -INFINITY, -INFINITY}, box_hi[3] = {INFINITY, INFINITY, INFINITY};   // around the spheres in groups (not the tail's)
 };
 
 static uint32_t spread10(uint32_t v)
@@ -676,6 +677,24 @@ static void build_groups(const std::vector<float4> &geom, const std::vector<floa
     for (size_t g = 0; g < groups.size(); g++) gb[g] = {groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].R};
     pack_heads(gb, out.heads);
 
+    // the box around the grouped spheres, rounded outwards; any non-finite member: no box
+    {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        bool finite = !groups.empty();
+        for (const Group &g : groups)
+            for (uint32_t i : g.members) {
+                const double cc[3] = {geom[i].x, geom[i].y, geom[i].z}, r = std::fabs((double)radius[i]);
+                for (int a = 0; a < 3; a++) {
+                    finite = finite && std::isfinite(cc[a]) && std::isfinite(r);
+                    blo[a] = std::min(blo[a], cc[a] - r); bhi[a] = std::max(bhi[a], cc[a] + r);
+                }
+            }
+        for (int a = 0; a < 3 && finite; a++) {
+            out.box_lo[a] = std::nextafterf((float)blo[a], -INFINITY);
+            out.box_hi[a] = std::nextafterf((float)bhi[a], INFINITY);
+        }
+    }
+
     // super-groups: RT_SUPER_GROUPS consecutive groups (Morton neighbours), bounded the same way
     out.n_supers = (int)((groups.size() + RT_SUPER_GROUPS - 1) / RT_SUPER_GROUPS);
     std::vector<std::array<double, 4>> sb(out.n_supers);
@@ -872,6 +891,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
     ctx->scene.n_supers2 = 0;
     ctx->scene.beam_max_rho = ctx->scene.beam_max_chord2 = -1.0f;
     ctx->scene.far_bound = INFINITY;
+    for (int a = 0; a < 3; a++) { ctx->scene.box_lo[a] = -INFINITY; ctx->scene.box_hi[a] = INFINITY; }
     ctx->scene_grouped = ctx->scene;
     ctx->scene_grouped.pairs = (const float4 *)(base + off_gpairs);
     ctx->scene_grouped.sph_id = (const int32_t *)(base + off_gids);
@@ -934,6 +954,7 @@ int rt_upload_scene(rt_context *ctx, const rt_object *objs, int32_t n, const rt_
         // fraction 17.8 / 8.6, a quarter 21.2 / 7.9)
         ctx->far_bound_sorted = ctx->scene_grouped.far_bound * 0.25f;
     }
+    for (int a = 0; a < 3; a++) { ctx->scene_grouped.box_lo[a] = grp.box_lo[a]; ctx->scene_grouped.box_hi[a] = grp.box_hi[a]; }
     for (int a = 0; a < 3; a++) ctx->scene_grouped.sigma[a] = grp.sigma[a];
     for (int a = 0; a < 3; a++) ctx->scene_grouped.metric[a] = grp.sigma[a] * grp.sigma[a];
     ctx->scene_grouped.slack_scale = grp.kappa * grp.kappa;

@@ -92,6 +92,8 @@ struct RtSceneDev {
     float far_bound;      // a lane whose filter allowance (2^-19 |pos|^2) reaches this is so far from the origin that the
                           // filter keeps spheres a good part of the scene's radius off its rays: its rays are tested
                           // against every sphere, one ray at a time across the wave (dense_sweep); +inf: never
+    float box_lo[3], box_hi[3];   // the box around the spheres under bounds (centre -/+ |radius|; -inf/+inf: unknown): a ray that
+                          // has left it has nothing more to hit among them (distance culling, rt_sweep_kernel.inc)
 };
 
 struct RtFrameDev {

@@ -129,6 +129,7 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
                                                bool hand_over, bool keep, Segment &next_seg, unsigned &next_rec, bool &next_alive)
 {
     const int lane = threadIdx.x & 63;
+    RT_TICK(RG_HITPOINT);
     V3 pos = v3(0, 0, 0), refl = v3(0, 0, 0), n = v3(0, 0, 0);
     bool want_refl = false;
     int mat = 0;
@@ -202,6 +203,7 @@ __device__ __forceinline__ void sorted_segment(float4 *lds, bool alive, const Se
             e0 += ne;
         }
     }
+    RT_TICK(RG_AFTER);
     const bool push = alive && want_refl && next_hit && next.slot != INT_MIN;
     // queue the next level's entries: one atomic per wave for the slots, one per lane on its cell's counter
     SortedArg &so = fresh_sorted()->so;
@@ -285,6 +287,11 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
     const int lane = threadIdx.x & 63;
     unsigned n_refl = 0, n_shadow = 0, n_hits = 0;
     SweepCount cnt = {0u, 0u, 0u};
+#ifdef RT_REGION_TIMERS
+    if (threadIdx.x < RT_N_REGIONS) rt_region_acc[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { rt_region_last = __builtin_amdgcn_s_memtime(); rt_region_cur = RG_RAYGEN; }
+    __syncthreads();
+#endif
     if constexpr (LEVEL0) {
         ArgsPtr a0 = fresh_args();
         FrameArg &fr = a0->fr;
@@ -412,6 +419,12 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
         }
         flush_stats<STATS>(true, n_refl, n_shadow, n_hits, 0u, cnt);
     }
+#ifdef RT_REGION_TIMERS
+    RT_TICK(RG_RAYGEN);
+    __syncthreads();
+    if (fresh_args()->fr.region_cycles && threadIdx.x < RT_N_REGIONS && rt_region_acc[threadIdx.x])
+        atomicAdd(&fresh_args()->fr.region_cycles[threadIdx.x], (unsigned long long)rt_region_acc[threadIdx.x]);
+#endif
 }
 
 // cell counters of one level -> where each cell's entries start (exclusive prefix sum); one workgroup
