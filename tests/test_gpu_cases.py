@@ -554,9 +554,41 @@ def test_grouped_sweep_edge_scenes(capi, oracle, gpu_ctx):
         for depth, spp in ((5, 4), (15, 1)):
             p = capi.render_params(w, h, depth, spp)
             rgb_o, f32_o, _ = oracle.render(objs, cam, p, threads=8)
-            rgb_g, f32_g = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, sweep=capi.RT_SWEEP_GROUPED)
-            d = np.count_nonzero(f32_o.view(np.uint32) != f32_g.view(np.uint32))
-            assert d == 0 and np.array_equal(rgb_o, rgb_g), f"{name} depth {depth} spp {spp}: {d} words differ"
+            for sweep in (capi.RT_SWEEP_GROUPED, capi.RT_SWEEP_SORTED):      # (sorted: distance culling, the box around the grouped spheres -- unknown with non-finite ones)
+                rgb_g, f32_g = render_gpu(capi, gpu_ctx, objs, cam, w, h, depth, spp, sweep=sweep)
+                d = np.count_nonzero(f32_o.view(np.uint32) != f32_g.view(np.uint32))
+                assert d == 0 and np.array_equal(rgb_o, rgb_g), f"{name} depth {depth} spp {spp} sweep {sweep}: {d} words differ"
+
+
+@pytest.mark.parametrize("side,scale", [(24, 1.0), (24, 250.0), (80, 1.0), (80, 40.0)])
+def test_sorted_sweep_culling_layers(capi, oracle, gpu_ctx, side, scale):
+    """A layer of mirror spheres over a mirror floor seen at a grazing angle, emitters low at the sides: reflection rays
+    that skim the layer (distance culling: the hit so far, the floor's hit, the way out of the box around the spheres),
+    hit points on the floor out to the horizon (far segments: the bounds of the super-groups before the dense sweep, rays
+    that stay clear of the box).  Bit-identical to the oracle at two scales, in both layouts of the bounds."""
+    M, S, P = capi.material, capi.sphere, capi.tiled_plane
+    rng = np.random.default_rng(side)
+    items = []
+    for i in range(side):
+        for j in range(side):
+            r = float(rng.uniform(.25, .6))
+            items.append(S(M(tuple(rng.random(3)), (.9, .9, .9), float(rng.choice([0.0, .5, .9]))),
+                           ((1.5 * (i - side / 2) + float(rng.uniform(-.2, .2))) * scale, (r + float(rng.uniform(0, .4))) * scale, (1.5 * (j - side / 2)) * scale), r * scale))
+    half = 0.75 * side
+    for z in (-half, 0.0, half):
+        items.append(S(M((1, 1, 1), (0, 0, 0), 0.0, (1, 1, 1)), (-(half + 4) * scale, 5 * scale, z * scale), 1.5 * scale))
+        items.append(S(M((1, 1, 1), (0, 0, 0), 0.0, (1, 1, 1)), ((half + 4) * scale, 9 * scale, z * scale), 1.5 * scale))
+    items.append(P((0, 0, 0), (0, 1, 0), M((.8, .8, .8), (.5, .5, .5), 0.6), M((.1, .1, .1), (.5, .5, .5), 0.6)))
+    objs = capi.objects(items)
+    w, h = 192, 108
+    cam = capi.camera_init((0, 3 * scale, (half + 10) * scale), (0, -.12, -1), 70.0, w, h)
+    p = capi.render_params(w, h, 6, 1, outputs=capi.RT_OUT_RGBA8 | capi.RT_OUT_F32X4)
+    rgb_o, f32_o, _ = oracle.render(objs, cam, p, threads=16)
+    for sweep in (capi.RT_SWEEP_SORTED, capi.RT_SWEEP_GROUPED):
+        rgb_g, f32_g = render_gpu(capi, gpu_ctx, objs, cam, w, h, 6, 1, sweep=sweep)
+        d = np.count_nonzero(f32_o.view(np.uint32) != f32_g.view(np.uint32))
+        assert d == 0 and np.array_equal(rgb_o, rgb_g), f"side {side} scale {scale} sweep {sweep}: {d} words differ"
+    assert len(np.unique(rgb_o.reshape(-1, 3), axis=0)) > 100       # (a picture, not a flat field)
 
 
 def _circular_lens(n, seed, radius=0.14):
