@@ -44,6 +44,9 @@
 #ifndef RT_DENSE_PRUNE
 #define RT_DENSE_PRUNE 1
 #endif
+#ifndef RT_BOX_SKIP_WALK
+#define RT_BOX_SKIP_WALK 1
+#endif
 #include "rt_sweep_kernel.inc"
 
 namespace {
