@@ -376,8 +376,10 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_GROUPED) void sorted_level_ke
         unsigned *const next_far0 = sa->so.count_kept + (RT_MAX_LEVELS + 1);
         auto take = [&](unsigned prev) -> unsigned {
             if (level != 0) return prev == 0xffffffffu ? blockIdx.x : prev + gridDim.x;
-            unsigned i = 0;
-            if (lane == 0) i = atomicAdd(next_far0, 1u);
+            // (a look before the atomic: the catch-up launch's 8 192 waves mostly find the queue taken, and 8 192 atomics on one
+            // word are 90 us of an otherwise empty launch; the counter only grows, so "taken" is final)
+            unsigned i = *reinterpret_cast<volatile unsigned *>(next_far0);
+            if (lane == 0 && i < count) i = atomicAdd(next_far0, 1u);
             return (unsigned)__builtin_amdgcn_readfirstlane((int)i);
         };
         for (unsigned i = take(0xffffffffu); i < count; i = take(i)) {
