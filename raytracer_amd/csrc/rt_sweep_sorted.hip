@@ -45,7 +45,7 @@
 #define RT_DENSE_PRUNE 1
 #endif
 #ifndef RT_BOX_SKIP_WALK
-#define RT_BOX_SKIP_WALK 1
+#define RT_BOX_SKIP_WALK 3
 #endif
 #include "rt_sweep_kernel.inc"
 
