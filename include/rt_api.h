@@ -114,7 +114,7 @@ enum {
 /* How a ray visits the sphere list.  Every choice gives the same image, bit for bit. */
 enum {
     RT_SWEEP_AUTO = 0,   /* flat below 64 spheres, grouped from there on; sorted for scenes of more than
-                            4096 spheres when the render has 2^18 paths or more, its buffers fit and
+                            4096 spheres when the render has 98 304 paths or more, its buffers fit and
                             nothing rules it out (rt_render_noalloc, RT_OUT_COST)                   */
     RT_SWEEP_FLAT = 1,   /* every ray is tested against every sphere, list streamed through LDS:
                             FindNearestObject's loop (main.cpp:65-82) as it stands                 */

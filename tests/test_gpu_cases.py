@@ -465,7 +465,7 @@ def test_sorted_sweep_options(capi, oracle, gpu_ctx, monkeypatch):
     gpu_ctx.upload_scene(objs, cam)
     with pytest.raises(capi.RtError, match="RT_OUT_COST"):
         gpu_ctx.render(capi.render_params(w, h, 5, 1, outputs=capi.RT_OUT_F32X4 | capi.RT_OUT_COST, stats=True, sweep=capi.RT_SWEEP_SORTED))
-    # RT_SWEEP_AUTO resolves to it for a large scene at 2^18 paths or more and not below (rt_stats.sweep), also inside a context
+    # RT_SWEEP_AUTO resolves to it for a large scene at 3 * 2^15 paths or more and not below (rt_stats.sweep), also inside a context
     # over several devices, whose parts each hold their own buffers and side stream
     w2, h2 = 1024, 576
     objs2, cam2 = capi.make_scene(capi.RT_SCENE_GRID16K, w2, h2)
@@ -479,7 +479,7 @@ def test_sorted_sweep_options(capi, oracle, gpu_ctx, monkeypatch):
         multi.upload_scene(objs2, cam2)
         for plan in (capi.RT_PLAN_STRIPS, capi.RT_PLAN_BANDS):
             multi.render(capi.render_params(w2, h2, 5, 1, outputs=both, device_plan=plan))
-            if plan == capi.RT_PLAN_STRIPS:            # (every part has half the paths; a cost-balanced band may fall below 2^18 and go one-launch)
+            if plan == capi.RT_PLAN_STRIPS:            # (every part has half the paths; a cost-balanced band may fall below the threshold and go one-launch)
                 assert multi.stats()["sweep"] == capi.RT_SWEEP_SORTED
             assert _same_frame(want, (multi.download(capi.RT_FMT_RGB8, w2, h2), multi.download(capi.RT_FMT_F32X4, w2, h2))), plan
     finally:
